@@ -1,0 +1,147 @@
+/*
+ * mi355pt.h -- C-ABI of the MI355X-native path-tracing render loop (libmi355pt.so).
+ *
+ * Drop-in boundary for the hot path of jctemp/owl-path-tracer: everything between
+ * `owlLaunch2D(ray_gen, W, H, lp)` (path_tracer/src/application.cpp:366) and the framebuffer being
+ * readable, i.e. ray_gen / trace_path / triangle_hit / miss (path_tracer/src/device/device.cu:113-293),
+ * the OptiX traversal they call, and the host->device contract that application.cpp fills in
+ * (launch_params_data, ray_gen_data, entity_data: path_tracer/src/device/device_global.hpp:38-74).
+ * The reference has no FFI of its own; each entry point below names the reference call(s) it replaces.
+ *
+ * Plain C, POD structs, plain pointers and sizes; no C++/torch types cross this boundary.  Every call
+ * returns 0 on success or a negative PT_E_* code (no exception crosses the ABI; message via
+ * pt_last_error).  A context is bound to one GPU and is not thread-safe (same as the reference: single
+ * host thread, application.cpp).  Caller owns every input array (copied during the call) and every
+ * output array; the library owns device memory, the BVH and its stream.
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+#define PT_MAT_FLOATS 17 /* material_data: device_global.hpp:19-36, 68 bytes, field order kept */
+
+enum {
+    PT_OK = 0,
+    PT_E_INVALID = -1,   /* bad argument (the reference would throw std::runtime_error / trap) */
+    PT_E_NO_DEVICE = -2, /* no usable gfx950 device / HIP runtime failure at create */
+    PT_E_HIP = -3,       /* a HIP call failed (message has the HIP error string) */
+    PT_E_NO_SCENE = -4,  /* render before upload ("no geometries", application.cpp:133) */
+    PT_E_LIMIT = -5      /* scene exceeds an internal limit (BVH depth / index range) */
+};
+
+typedef struct pt_ctx pt_ctx;
+
+typedef struct pt_config {
+    int32_t device;   /* HIP device ordinal (reference: create_context(nullptr, 1), application.cpp:62) */
+    int32_t reserved; /* must be 0 */
+} pt_config;
+
+/* One entity = one OBJ object that matched a material (application.cpp:166-179, :186-247).
+ * Arrays as produced by create_mesh (utils/mesh_loader.cpp:9-83). */
+typedef struct pt_mesh {
+    const float* vertices;   /* n_vertices * 3   (vertex_buffer, application.cpp:197) */
+    const float* normals;    /* n_normals * 3    (normal_buffer, :198) -- must cover every vertex index */
+    const float* texcoords;  /* n_texcoords * 2  (texcoords_buffer, :200) or NULL */
+    const int32_t* indices;  /* n_triangles * 3  (index_buffer, :199) */
+    int32_t n_vertices, n_normals, n_texcoords, n_triangles;
+    int32_t material_index;  /* entity_data.material_index (:212); <0 => material_data{} defaults (device.cu:150-154) */
+    int32_t texture_index;   /* index into textures[] or <0 (entity_data.has_texture/texture, :236-243) */
+} pt_mesh;
+
+/* RGBA8 image, row 0 = v = 0, i.e. AFTER the vertical flip the reference applies at load
+ * (application.cpp:229-234, utils/image_buffer.cpp:50-55); sampled nearest / clamp / normalised
+ * coordinates (owl.hpp:248-257). */
+typedef struct pt_texture {
+    int32_t width, height;
+    const uint32_t* rgba8;
+} pt_texture;
+
+/* launch_params_data environment fields (device_global.hpp:59-63, application.cpp:285-289) */
+typedef struct pt_env {
+    int32_t use_map;    /* environment_use  (only effective with a non-empty map, device.cu:138) */
+    int32_t use_auto;   /* environment_auto */
+    float color[3];     /* environment_color */
+    float intensity;    /* environment_intensity */
+    pt_texture map;     /* environment_map; width == 0 => none */
+} pt_env;
+
+/* camera_data (camera.hpp:14-20), 48 bytes, produced by to_camera_data (camera.cpp:3-21) */
+typedef struct pt_camera {
+    float origin[3], llc[3], horizontal[3], vertical[3];
+} pt_camera;
+
+/* Work counters of the last counted render (pt_set_option "count" = 1). One sample = one camera path. */
+typedef struct pt_stats {
+    double kernel_ms;       /* sum of render-kernel durations of the last pt_render*, HIP events on the launch stream */
+    int32_t launches;       /* render-kernel launches in the last pt_render* */
+    int32_t vgprs, sgprs, lds_bytes, block, grid, stack_entries; /* launch geometry of the render kernel */
+    uint64_t samples, rays, nodes, tris, scatters, env_misses, nan_retries; /* valid when counted */
+    uint64_t bvh_nodes, bvh_depth, n_triangles;
+    double bvh_build_ms;
+} pt_stats;
+
+/* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
+pt_ctx* pt_create(const pt_config* cfg);          /* NULL on failure; pt_last_error(NULL) has the reason */
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(const pt_ctx* ctx);     /* ctx may be NULL (creation errors) */
+int pt_abi_version(void);
+
+/* ---- scene (replaces bind_sbt_data + init_owl_world: application.cpp:184-294, :131-140) ----
+ * Copies the meshes, builds the BVH2 on the host and uploads everything to HBM. */
+int pt_upload_scene(pt_ctx* ctx, const pt_mesh* meshes, int32_t n_meshes, const float* materials, int32_t n_materials,
+                    const pt_texture* textures, int32_t n_textures, const int32_t* material_texture, const pt_env* env);
+/* material_texture: optional n_materials ints (texture index per material or <0).  NULL => derived from
+ * pt_mesh.texture_index of the entities using the material (the reference ties the texture to the
+ * material's filename, parser.cpp:32-35 / application.cpp:214-243). */
+
+/* replaces reset_field (application.cpp:297-304): re-upload the material table, BVH untouched */
+int pt_set_materials(pt_ctx* ctx, const float* materials, int32_t n_materials);
+int pt_set_environment(pt_ctx* ctx, const pt_env* env);
+
+/* ---- pixel ownership (multi-GPU sharding; no reference counterpart: the reference is single-GPU) ----
+ * Default: this context renders every pixel.  Launch-index pixel id = x + W*y (ray_gen's pixelId). */
+int pt_set_pixel_shard(pt_ctx* ctx, int32_t rank, int32_t world_size, int32_t tile);
+/* Host-only helper (no GPU needed): ids owned by `rank` when tile x tile pixel tiles are dealt
+ * round-robin in row-major tile order.  Returns the count (writes at most cap ids); <0 on error. */
+int64_t pt_shard_pixels(int32_t width, int32_t height, int32_t tile, int32_t rank, int32_t world_size, uint32_t* ids, int64_t cap);
+
+/* ---- render (replaces owlLaunch2D + framebuffer read-back: application.cpp:363-369) ----
+ * Blocking.  out_rgb: W*H*3 floats, linear, averaged over max_samples, stored at
+ * x + W*(H-1-y) like the reference framebuffer (device.cu:251); pixels not owned by this context
+ * are 0.  out_rgba8 (optional): owl::make_rgba of the same values (device.cu:252-253). */
+int pt_render(pt_ctx* ctx, const pt_camera* cam, int32_t width, int32_t height, int32_t max_samples, int32_t max_path_depth,
+              float* out_rgb, uint32_t* out_rgba8);
+/* Same render, asynchronous on `stream` (a hipStream_t; NULL = the context's own stream), result left
+ * in HBM at d_out_rgb (device pointer, W*H*3 floats) for the caller's RCCL reduce.  d_out_rgba8 optional. */
+int pt_render_device(pt_ctx* ctx, const pt_camera* cam, int32_t width, int32_t height, int32_t max_samples, int32_t max_path_depth,
+                     void* d_out_rgb, void* d_out_rgba8, void* stream);
+int pt_synchronize(pt_ctx* ctx);
+
+/* options: "spp_per_launch" (0 = whole job in one launch), "count" (0/1: instrumented kernel that fills
+ * pt_stats counters), "blocks_per_cu", "leaf_size" (next upload) */
+int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);
+int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+
+/* ---- host utilities ---- */
+/* to_camera_data (camera.cpp:3-21) */
+void pt_to_camera_data(const float look_from[3], const float look_at[3], const float look_up[3], float vertical_fov_deg,
+                       int32_t width, int32_t height, pt_camera* out);
+
+/* ---- validation hooks (used by tests/ only; never on the render path) ---- */
+/* Closest hit through the PRODUCT BVH walked on the host: validates the host builder without a GPU. */
+int pt_debug_closest_hit_host(pt_ctx* ctx, const float org[3], const float dir[3], float tmin, float tmax,
+                              float* t, float* u, float* v, int32_t* prim);
+/* Batched device-side evaluation of the kernel's building blocks on the GPU (op codes in pt_kernel.hip):
+ * lets the parity tests compare them bit-for-bit with the oracle.  in/out are host arrays. */
+int pt_debug_eval(pt_ctx* ctx, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

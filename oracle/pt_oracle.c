@@ -1129,6 +1129,7 @@ static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_co
     v3 radiance = vs(0.0f);
     v3 throughput = vs(1.0f);
     int sampled_lobe = LOBE_NONE;
+    int retries = 0;
 
     for (int depth = 0; depth < rc->max_depth; ++depth) {
         hit h;
@@ -1195,9 +1196,13 @@ static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_co
         if (dm_isinf(f.x) || dm_isinf(f.y) || dm_isinf(f.z) || dm_isnan(f.x) || dm_isnan(f.y) || dm_isnan(f.z)) {
             /* device.cu:196-201: --depth; continue; -> the SAME ray is traced again with fresh RNG draws */
             if (cnt) cnt->nan_retries++;
+            /* safety net shared with the HIP kernel: the reference would spin forever on a hit whose
+               BSDF is NaN for every draw; after 64 consecutive retries the path ends with zero radiance */
+            if (++retries > 64) break;
             --depth;
             continue;
         }
+        retries = 0;
 
         /* device.cu:204-205 */
         float aci = dm_abs(cos_theta(local_wi));

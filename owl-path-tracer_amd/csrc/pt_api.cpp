@@ -1,0 +1,619 @@
+// pt_api.cpp -- implementation of the C-ABI declared in include/mi355pt.h (host side, HIP runtime).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "pt_bvh.h"
+#include "pt_types.h"
+
+extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int grid, size_t lds_bytes, hipStream_t stream, int count);
+extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
+                                      size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t pt_kernel_attributes(int count, int* vgprs, int* sgprs, int* static_lds, int* max_blocks_per_cu, size_t lds_bytes);
+extern "C" int pt_kernel_block(void);
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct HostTexture {
+    int w = 0, h = 0;
+    std::vector<uint32_t> px;
+};
+
+} // namespace
+
+struct pt_ctx {
+    int device = -1;
+    bool host_only = false;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+    std::string err;
+
+    // host copies
+    PtBvh bvh;
+    std::vector<PtShade> shade;
+    std::vector<float> materials; // n * PT_MAT_STRIDE
+    int n_materials = 0;
+    std::vector<int32_t> material_texture;
+    std::vector<HostTexture> textures;
+    pt_env env{};
+    HostTexture env_map;
+    bool have_scene = false;
+
+    // device
+    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out;
+    std::vector<void*> d_textures;
+
+    // pixel queue
+    int q_w = 0, q_h = 0, q_rank = 0, q_world = 1, q_tile = 16;
+    int rank = 0, world = 1, tile = 16;
+    uint32_t n_pixels = 0;
+    bool queue_valid = false;
+
+    // options
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48;
+
+    pt_stats stats{};
+    int last_launches = 0;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) return fail(c, PT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+int ensure(pt_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return PT_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return PT_OK;
+}
+
+int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes)
+{
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return PT_OK;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+void copy_env(pt_ctx* c, const pt_env* env)
+{
+    c->env = *env;
+    c->env_map.w = c->env_map.h = 0;
+    c->env_map.px.clear();
+    if (env->map.width > 0 && env->map.height > 0 && env->map.rgba8) {
+        c->env_map.w = env->map.width;
+        c->env_map.h = env->map.height;
+        c->env_map.px.assign(env->map.rgba8, env->map.rgba8 + (size_t)env->map.width * env->map.height);
+    }
+    c->env.map.rgba8 = nullptr;
+}
+
+int upload_env(pt_ctx* c)
+{
+    if (c->host_only) return PT_OK;
+    if (c->env_map.w > 0) return upload(c, c->d_env, c->env_map.px.data(), c->env_map.px.size() * 4);
+    return PT_OK;
+}
+
+int upload_materials(pt_ctx* c)
+{
+    if (c->host_only) return PT_OK;
+    return upload(c, c->d_materials, c->materials.data(), c->materials.size() * sizeof(float));
+}
+
+void pack_materials(pt_ctx* c, const float* materials, int n)
+{
+    c->n_materials = n;
+    c->materials.assign((size_t)n * PT_MAT_STRIDE, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        float* dst = &c->materials[(size_t)i * PT_MAT_STRIDE];
+        std::memcpy(dst, materials + (size_t)i * PT_MAT_FLOATS, PT_MAT_FLOATS * sizeof(float));
+        int32_t slot = (i < (int)c->material_texture.size()) ? c->material_texture[i] : -1;
+        std::memcpy(dst + 17, &slot, 4);
+    }
+}
+
+// Pixel ids owned by (rank, world): tile x tile tiles dealt round-robin on (tx + ty) % world; inside a tile the
+// ids are emitted in 8x8 blocks so that the 64 lanes of a wave start on one compact screen patch.
+int64_t shard_pixels(int W, int H, int tile, int rank, int world, uint32_t* ids, int64_t cap)
+{
+    if (W <= 0 || H <= 0 || world < 1 || rank < 0 || rank >= world) return -1;
+    if (tile < 8) tile = 8;
+    tile = (tile + 7) & ~7;
+    int ntx = (W + tile - 1) / tile, nty = (H + tile - 1) / tile;
+    int64_t n = 0;
+    for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx) {
+            if ((tx + ty) % world != rank) continue;
+            for (int by = 0; by < tile; by += 8)
+                for (int bx = 0; bx < tile; bx += 8)
+                    for (int y = 0; y < 8; ++y)
+                        for (int x = 0; x < 8; ++x) {
+                            int px = tx * tile + bx + x, py = ty * tile + by + y;
+                            if (px >= W || py >= H) continue;
+                            if (ids && n < cap) ids[n] = (uint32_t)px + (uint32_t)W * (uint32_t)py;
+                            ++n;
+                        }
+        }
+    return n;
+}
+
+int ensure_queue(pt_ctx* c, int W, int H)
+{
+    if (c->queue_valid && c->q_w == W && c->q_h == H && c->q_rank == c->rank && c->q_world == c->world && c->q_tile == c->tile) return PT_OK;
+    int64_t n = shard_pixels(W, H, c->tile, c->rank, c->world, nullptr, 0);
+    if (n < 0) return fail(c, PT_E_INVALID, "invalid pixel shard (%d of %d)", c->rank, c->world);
+    std::vector<uint32_t> ids((size_t)n);
+    shard_pixels(W, H, c->tile, c->rank, c->world, ids.data(), n);
+    int rc = upload(c, c->d_pixels, ids.data(), ids.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // ids is a local
+    c->n_pixels = (uint32_t)n;
+    c->q_w = W; c->q_h = H; c->q_rank = c->rank; c->q_world = c->world; c->q_tile = c->tile;
+    c->queue_valid = true;
+    return PT_OK;
+}
+
+void fill_params(pt_ctx* c, PtKernelParams& P)
+{
+    std::memset(&P, 0, sizeof(P));
+    P.nodes = (const PtNode*)c->d_nodes.p;
+    P.tris = (const PtTri*)c->d_tris.p;
+    P.shade = (const PtShade*)c->d_shade.p;
+    P.materials = (const float*)c->d_materials.p;
+    P.textures = (const PtTexDesc*)c->d_texdesc.p;
+    P.env_map.texels = c->env_map.w > 0 ? (const uint32_t*)c->d_env.p : nullptr;
+    P.env_map.width = c->env_map.w;
+    P.env_map.height = c->env_map.h;
+    for (int i = 0; i < 3; ++i) P.env_color[i] = c->env.color[i];
+    P.env_intensity = c->env.intensity;
+    P.env_use_map = c->env.use_map;
+    P.env_use_auto = c->env.use_auto;
+    P.root = c->bvh.root;
+    P.n_tris = (int)c->bvh.tris.size();
+    P.n_materials = c->n_materials;
+    P.stack_entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
+}
+
+size_t lds_bytes_for(const pt_ctx* c)
+{
+    int entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
+    return (size_t)entries * pt_kernel_block() * 4 + (size_t)c->n_materials * PT_MAT_STRIDE * 4;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+pt_ctx* pt_create(const pt_config* cfg)
+{
+    int dev = cfg ? cfg->device : 0;
+    pt_ctx* c = new pt_ctx();
+    c->device = dev;
+    if (dev < 0) { // host-only validation context: scene/BVH/sharding work, every render call fails loudly
+        c->host_only = true;
+        return c;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || dev >= n) {
+        fail(nullptr, PT_E_NO_DEVICE, "no usable HIP device (count=%d, requested=%d): %s", n, dev, hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        fail(nullptr, PT_E_NO_DEVICE, "hipSetDevice/hipGetDeviceProperties failed for device %d", dev);
+        delete c;
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, PT_E_NO_DEVICE, "device %d is %s; this library ships gfx950 (MI355X) code only", dev, prop.gcnArchName);
+        delete c;
+        return nullptr;
+    }
+    c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        fail(nullptr, PT_E_HIP, "stream/event creation failed");
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void pt_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    if (!c->host_only) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out};
+        for (DevBuf* b : bufs) release(*b);
+        for (void* p : c->d_textures) (void)hipFree(p);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int pt_set_option(pt_ctx* c, const char* key, int64_t value)
+{
+    if (!c || !key) return PT_E_INVALID;
+    std::string k(key);
+    if (k == "spp_per_launch") c->spp_per_launch = (int)(value < 0 ? 0 : value);
+    else if (k == "count") c->count = value ? 1 : 0;
+    else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
+    else if (k == "leaf_size") c->leaf_size = (int)value;
+    else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
+    else return fail(c, PT_E_INVALID, "unknown option '%s'", key);
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const float* materials, int32_t n_materials,
+                    const pt_texture* textures, int32_t n_textures, const int32_t* material_texture, const pt_env* env)
+{
+    if (!c) return PT_E_INVALID;
+    if (n_meshes < 0 || n_materials < 0 || n_textures < 0 || (n_meshes > 0 && !meshes) || (n_materials > 0 && !materials) ||
+        (n_textures > 0 && !textures))
+        return fail(c, PT_E_INVALID, "pt_upload_scene: null array with non-zero count");
+    if (!c->host_only) HIP_TRY(c, hipSetDevice(c->device));
+
+    // ---- flatten entities to one record per triangle, global order = entity order then face order ----
+    size_t n_tris = 0;
+    for (int m = 0; m < n_meshes; ++m) {
+        if (meshes[m].n_triangles < 0) return fail(c, PT_E_INVALID, "mesh %d: negative triangle count", m);
+        n_tris += (size_t)meshes[m].n_triangles;
+    }
+    if (n_tris > (size_t)(1u << 28)) return fail(c, PT_E_LIMIT, "too many triangles (%zu)", n_tris);
+    std::vector<float> pos(n_tris * 9);
+    c->shade.assign(n_tris, PtShade{});
+    c->material_texture.assign((size_t)n_materials, -1);
+    if (material_texture)
+        for (int i = 0; i < n_materials; ++i) c->material_texture[i] = material_texture[i];
+    size_t g = 0;
+    for (int m = 0; m < n_meshes; ++m) {
+        const pt_mesh& ms = meshes[m];
+        if (ms.n_triangles > 0 && (!ms.vertices || !ms.indices)) return fail(c, PT_E_INVALID, "mesh %d: null vertices/indices", m);
+        if (ms.material_index >= n_materials) return fail(c, PT_E_INVALID, "mesh %d: material index %d out of range", m, ms.material_index);
+        if (ms.texture_index >= n_textures) return fail(c, PT_E_INVALID, "mesh %d: texture index %d out of range", m, ms.texture_index);
+        if (ms.texture_index >= 0 && ms.material_index >= 0 && !material_texture) c->material_texture[ms.material_index] = ms.texture_index;
+        const bool textured = ms.texture_index >= 0;
+        for (int t = 0; t < ms.n_triangles; ++t, ++g) {
+            PtShade& sh = c->shade[g];
+            sh.material = ms.material_index;
+            for (int k = 0; k < 3; ++k) {
+                int32_t vi = ms.indices[(size_t)t * 3 + k];
+                if (vi < 0 || vi >= ms.n_vertices) return fail(c, PT_E_INVALID, "mesh %d: vertex index out of range", m);
+                // the reference traps on an out-of-bounds normal/texcoord fetch (macros.hpp:5-11)
+                if (!ms.normals || vi >= ms.n_normals) return fail(c, PT_E_INVALID, "mesh %d: no normal for vertex %d", m, vi);
+                if (textured && (!ms.texcoords || vi >= ms.n_texcoords)) return fail(c, PT_E_INVALID, "mesh %d: no texcoord for vertex %d", m, vi);
+                std::memcpy(&pos[g * 9 + (size_t)k * 3], ms.vertices + (size_t)vi * 3, 12);
+                float* nd = k == 0 ? sh.n0 : (k == 1 ? sh.n1 : sh.n2);
+                std::memcpy(nd, ms.normals + (size_t)vi * 3, 12);
+                if (ms.texcoords && vi < ms.n_texcoords) std::memcpy(&sh.tc[k * 2], ms.texcoords + (size_t)vi * 2, 8);
+            }
+        }
+    }
+
+    // ---- BVH (replaces owlGroupBuildAccel, application.cpp:135-139) ----
+    auto t0 = std::chrono::steady_clock::now();
+    pt_bvh_build(pos.data(), (int32_t)n_tris, c->leaf_size, c->max_bvh_depth, &c->bvh);
+    auto t1 = std::chrono::steady_clock::now();
+    c->stats.bvh_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    c->stats.bvh_nodes = c->bvh.nodes.size();
+    c->stats.bvh_depth = (uint64_t)c->bvh.depth;
+    c->stats.n_triangles = n_tris;
+    if (c->bvh.depth > PT_MAX_STACK) return fail(c, PT_E_LIMIT, "BVH depth %d exceeds %d", c->bvh.depth, PT_MAX_STACK);
+
+    // ---- textures, materials, environment ----
+    c->textures.assign((size_t)n_textures, HostTexture{});
+    for (int i = 0; i < n_textures; ++i) {
+        if (textures[i].width <= 0 || textures[i].height <= 0 || !textures[i].rgba8) return fail(c, PT_E_INVALID, "texture %d is empty", i);
+        c->textures[i].w = textures[i].width;
+        c->textures[i].h = textures[i].height;
+        c->textures[i].px.assign(textures[i].rgba8, textures[i].rgba8 + (size_t)textures[i].width * textures[i].height);
+    }
+    pack_materials(c, materials, n_materials);
+    pt_env def{};
+    copy_env(c, env ? env : &def);
+    c->have_scene = true;
+    if (c->host_only) return PT_OK;
+
+    int rc;
+    if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
+    if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
+    if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
+    for (void* p : c->d_textures) (void)hipFree(p);
+    c->d_textures.clear();
+    std::vector<PtTexDesc> descs((size_t)n_textures);
+    for (int i = 0; i < n_textures; ++i) {
+        void* p = nullptr;
+        size_t bytes = c->textures[i].px.size() * 4;
+        HIP_TRY(c, hipMalloc(&p, bytes));
+        c->d_textures.push_back(p);
+        HIP_TRY(c, hipMemcpyAsync(p, c->textures[i].px.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        descs[i].texels = (const uint32_t*)p;
+        descs[i].width = c->textures[i].w;
+        descs[i].height = c->textures[i].h;
+    }
+    if ((rc = upload(c, c->d_texdesc, descs.data(), descs.size() * sizeof(PtTexDesc)))) return rc;
+    if ((rc = upload_materials(c))) return rc;
+    if ((rc = upload_env(c))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_set_materials(pt_ctx* c, const float* materials, int32_t n_materials)
+{
+    if (!c || !materials || n_materials < 0) return PT_E_INVALID;
+    if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "pt_set_materials before pt_upload_scene");
+    if (n_materials != c->n_materials) return fail(c, PT_E_INVALID, "material count changed (%d -> %d); re-upload the scene", c->n_materials, n_materials);
+    pack_materials(c, materials, n_materials);
+    if (c->host_only) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = upload_materials(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_set_environment(pt_ctx* c, const pt_env* env)
+{
+    if (!c || !env) return PT_E_INVALID;
+    copy_env(c, env);
+    if (c->host_only) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = upload_env(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_set_pixel_shard(pt_ctx* c, int32_t rank, int32_t world_size, int32_t tile)
+{
+    if (!c) return PT_E_INVALID;
+    if (world_size < 1 || rank < 0 || rank >= world_size || tile < 1) return fail(c, PT_E_INVALID, "bad shard %d/%d tile %d", rank, world_size, tile);
+    c->rank = rank;
+    c->world = world_size;
+    c->tile = tile;
+    return PT_OK;
+}
+
+int64_t pt_shard_pixels(int32_t width, int32_t height, int32_t tile, int32_t rank, int32_t world_size, uint32_t* ids, int64_t cap)
+{
+    return shard_pixels(width, height, tile, rank, world_size, ids, cap);
+}
+
+int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max_samples, int32_t max_depth, void* d_out_rgb,
+                     void* d_out_rgba8, void* stream_v)
+{
+    if (!c || !cam || !d_out_rgb) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: the HIP render path is required and there is no CPU fallback");
+    if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "no geometries (pt_upload_scene not called)");
+    if (W <= 0 || H <= 0 || max_samples <= 0 || max_depth < 0 || (int64_t)W * H > (int64_t)0x7fffffff)
+        return fail(c, PT_E_INVALID, "bad render size %dx%d spp %d depth %d", W, H, max_samples, max_depth);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    int rc = ensure_queue(c, W, H);
+    if (rc) return rc;
+
+    int S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
+    int n_launch = (max_samples + S - 1) / S;
+    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
+    if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
+    if (n_launch > 1) {
+        if ((rc = ensure(c, c->d_rng, (size_t)W * H * 4))) return rc;
+        if ((rc = ensure(c, c->d_accum, (size_t)W * H * 12))) return rc;
+    }
+    if (c->count) {
+        if ((rc = ensure(c, c->d_counters, sizeof(PtCounters)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(PtCounters), stream));
+    }
+
+    PtKernelParams P;
+    fill_params(c, P);
+    std::memcpy(P.cam, cam, sizeof(float) * 12);
+    P.pixel_ids = (const uint32_t*)c->d_pixels.p;
+    P.n_pixels = c->n_pixels;
+    P.rng_state = (uint32_t*)c->d_rng.p;
+    P.accum = (float*)c->d_accum.p;
+    P.out_rgb = (float*)d_out_rgb;
+    P.out_rgba8 = (uint32_t*)d_out_rgba8;
+    P.counters = c->count ? (PtCounters*)c->d_counters.p : nullptr;
+    P.width = W;
+    P.height = H;
+    P.max_samples = max_samples;
+    P.max_depth = max_depth;
+
+    size_t lds = lds_bytes_for(c);
+    int vg = 0, sg = 0, slds = 0, occ = 0;
+    HIP_TRY(c, pt_kernel_attributes(c->count, &vg, &sg, &slds, &occ, lds));
+    if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
+    int bpc = c->blocks_per_cu > 0 ? std::min(c->blocks_per_cu, occ) : occ;
+    const int block = pt_kernel_block();
+    long want = ((long)c->n_pixels + block - 1) / block;
+    int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
+
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    for (int l = 0; l < n_launch; ++l) {
+        P.queue_head = (uint32_t*)c->d_heads.p + l;
+        P.sample_begin = l * S;
+        P.sample_count = std::min(S, max_samples - l * S);
+        HIP_TRY(c, pt_launch_render(&P, grid, lds, stream, c->count));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->ev_pending = true;
+    c->last_launches = n_launch;
+    c->stats.vgprs = vg;
+    c->stats.sgprs = sg;
+    c->stats.lds_bytes = (int)lds + slds;
+    c->stats.block = block;
+    c->stats.grid = grid;
+    c->stats.stack_entries = P.stack_entries;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c)
+{
+    if (!c) return PT_E_INVALID;
+    if (c->host_only) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max_samples, int32_t max_depth, float* out_rgb, uint32_t* out_rgba8)
+{
+    if (!c || !cam || !out_rgb) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: the HIP render path is required and there is no CPU fallback");
+    if (W <= 0 || H <= 0) return fail(c, PT_E_INVALID, "bad render size %dx%d", W, H);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    size_t npx = (size_t)W * H;
+    if ((rc = ensure(c, c->d_out, npx * 12))) return rc;
+    if (out_rgba8 && (rc = ensure(c, c->d_out8, npx * 4))) return rc;
+    rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
+    if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx* c, pt_stats* out)
+{
+    if (!c || !out) return PT_E_INVALID;
+    if (!c->host_only && c->ev_pending) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.kernel_ms = ms;
+        c->stats.launches = c->last_launches;
+        c->ev_pending = false;
+        if (c->count && c->d_counters.p) {
+            PtCounters h;
+            HIP_TRY(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+            c->stats.samples = h.samples; c->stats.rays = h.rays; c->stats.nodes = h.nodes; c->stats.tris = h.tris;
+            c->stats.scatters = h.scatters; c->stats.env_misses = h.env_misses; c->stats.nan_retries = h.nan_retries;
+        }
+    }
+    *out = c->stats;
+    return PT_OK;
+}
+
+void pt_to_camera_data(const float look_from[3], const float look_at[3], const float look_up[3], float vfov, int32_t w, int32_t h, pt_camera* out)
+{
+    // camera.cpp:3-21; host code, host libm tan as in the reference.  dot/cross use the same fused forms as the device code.
+    auto dot = [](const float* a, const float* b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); };
+    auto cross = [](const float* a, const float* b, float* r) {
+        r[0] = std::fma(a[1], b[2], -(a[2] * b[1]));
+        r[1] = std::fma(a[2], b[0], -(a[0] * b[2]));
+        r[2] = std::fma(a[0], b[1], -(a[1] * b[0]));
+    };
+    auto normalize = [&](float* v) {
+        float s = 1.0f / std::sqrt(dot(v, v));
+        v[0] *= s; v[1] *= s; v[2] *= s;
+    };
+    const float pi = 3.14159265358979323f;
+    float aspect = (float)w / (float)h;
+    float theta = vfov * pi / 180.0f;
+    float hh = std::tan(theta / 2);
+    float vh = 2.0f * hh, vw = aspect * vh;
+    float W[3] = {look_from[0] - look_at[0], look_from[1] - look_at[1], look_from[2] - look_at[2]};
+    normalize(W);
+    float U[3], Vv[3];
+    cross(look_up, W, U);
+    normalize(U);
+    cross(W, U, Vv);
+    normalize(Vv);
+    for (int i = 0; i < 3; ++i) {
+        out->origin[i] = look_from[i];
+        out->horizontal[i] = vw * U[i];
+        out->vertical[i] = vh * Vv[i];
+        out->llc[i] = look_from[i] - out->horizontal[i] / 2.0f - out->vertical[i] / 2.0f - W[i];
+    }
+}
+
+int pt_debug_closest_hit_host(pt_ctx* c, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u, float* v, int32_t* prim)
+{
+    if (!c || !c->have_scene) return PT_E_NO_SCENE;
+    return pt_bvh_closest_hit_host(c->bvh, org, dir, tmin, tmax, t, u, v, prim) ? 1 : 0;
+}
+
+int pt_debug_eval(pt_ctx* c, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n)
+{
+    if (!c || !in || !out || n < 0 || in_stride < 1 || out_stride < 1) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_eval needs the GPU");
+    if (n == 0) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = upload(c, c->d_dbg_in, in, (size_t)n * in_stride * 4))) return rc;
+    if ((rc = ensure(c, c->d_dbg_out, (size_t)n * out_stride * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_dbg_out.p, 0, (size_t)n * out_stride * 4, c->stream));
+    PtKernelParams P;
+    fill_params(c, P);
+    if (!c->have_scene) { P.root = -1; P.stack_entries = 1; }
+    size_t lds = (size_t)P.stack_entries * pt_kernel_block() * 4;
+    HIP_TRY(c, pt_launch_debug(&P, op, (const float*)c->d_dbg_in.p, in_stride, (float*)c->d_dbg_out.p, out_stride, (long long)n, lds, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_dbg_out.p, (size_t)n * out_stride * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,267 @@
+// pt_bvh.cpp -- binned-SAH BVH2 builder producing the 64-byte node / 48-byte triangle layout of pt_types.h.
+#include "pt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; } }
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); } }
+    float half_area() const
+    {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0.0f)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    const float* pos;
+    std::vector<Box> tb;        // per-triangle bounds
+    std::vector<float> cen;     // per-triangle centroid * 3
+    std::vector<int32_t> order; // permutation being partitioned
+    PtBvh* out;
+    int leaf_size, max_depth;
+    float pad;
+
+    Box range_box(int lo, int hi) const
+    {
+        Box b;
+        b.reset();
+        for (int i = lo; i < hi; ++i) b.grow(tb[order[i]]);
+        return b;
+    }
+    static int levels_needed(int n, int leaf)
+    {
+        int l = 0;
+        long cap = leaf;
+        while (cap < n) { cap *= 2; ++l; }
+        return l; // internal levels a balanced split needs
+    }
+
+    void median_split(int lo, int hi, int axis, int mid)
+    {
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](int32_t a, int32_t b) {
+            float ca = cen[(size_t)a * 3 + axis], cb = cen[(size_t)b * 3 + axis];
+            return ca < cb || (ca == cb && a < b);
+        });
+    }
+
+    // returns child reference; depth = number of internal nodes on the path including the one created here
+    int32_t build(int lo, int hi, int depth, bool balanced)
+    {
+        int n = hi - lo;
+        if (n <= leaf_size) {
+            out->max_leaf = std::max(out->max_leaf, n);
+            return ~((lo << 3) | n);
+        }
+        Box cb;
+        cb.reset();
+        for (int i = lo; i < hi; ++i) cb.grow(&cen[(size_t)order[i] * 3]);
+        int remaining = max_depth - depth; // internal levels still available below this node (this one included)
+        if (!balanced && levels_needed(n, leaf_size) >= remaining) balanced = true;
+
+        int mid = -1;
+        if (!balanced) {
+            constexpr int NB = 16;
+            float best = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                float lo_c = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
+                if (!(ext > 0.0f)) continue;
+                Box bb[NB];
+                int cnt[NB];
+                for (int b = 0; b < NB; ++b) { bb[b].reset(); cnt[b] = 0; }
+                float scale = (float)NB / ext;
+                for (int i = lo; i < hi; ++i) {
+                    int id = order[i];
+                    int b = (int)((cen[(size_t)id * 3 + axis] - lo_c) * scale);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    bb[b].grow(tb[id]);
+                    cnt[b]++;
+                }
+                float ra[NB];
+                int rc[NB];
+                Box acc;
+                acc.reset();
+                int c = 0;
+                for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; ra[b] = acc.half_area(); rc[b] = c; }
+                acc.reset();
+                c = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    acc.grow(bb[b]);
+                    c += cnt[b];
+                    if (c == 0 || rc[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+                    if (cost < best) { best = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float lo_c = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
+                float scale = (float)16 / ext;
+                auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](int32_t id) {
+                    int b = (int)((cen[(size_t)id * 3 + best_axis] - lo_c) * scale);
+                    b = b < 0 ? 0 : (b >= 16 ? 15 : b);
+                    return b <= best_bin;
+                });
+                mid = (int)(it - order.begin());
+                if (mid == lo || mid == hi) mid = -1;
+            }
+        }
+        if (mid < 0) { // balanced / degenerate: object median along the widest centroid axis
+            int axis = 0;
+            float e = cb.mx[0] - cb.mn[0];
+            if (cb.mx[1] - cb.mn[1] > e) { axis = 1; e = cb.mx[1] - cb.mn[1]; }
+            if (cb.mx[2] - cb.mn[2] > e) axis = 2;
+            mid = lo + n / 2;
+            median_split(lo, hi, axis, mid);
+        }
+        int idx = (int)out->nodes.size();
+        out->nodes.emplace_back();
+        out->depth = std::max(out->depth, depth);
+        Box l = range_box(lo, mid), r = range_box(mid, hi);
+        int32_t lc = build(lo, mid, depth + 1, balanced);
+        int32_t rc = build(mid, hi, depth + 1, balanced);
+        PtNode& nd = out->nodes[idx];
+        for (int a = 0; a < 3; ++a) {
+            nd.lmin[a] = l.mn[a] - pad; nd.lmax[a] = l.mx[a] + pad;
+            nd.rmin[a] = r.mn[a] - pad; nd.rmax[a] = r.mx[a] + pad;
+        }
+        nd.left = lc;
+        nd.right = rc;
+        nd.pad[0] = nd.pad[1] = 0;
+        return idx;
+    }
+};
+
+} // namespace
+
+void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max_depth, PtBvh* out)
+{
+    out->nodes.clear();
+    out->tris.clear();
+    out->root = -1;
+    out->depth = 0;
+    out->max_leaf = 0;
+    out->pad = 0.0f;
+    if (n_tris <= 0) return;
+    leaf_size = std::max(1, std::min(7, leaf_size));
+    max_depth = std::max(2, std::min((int)PT_MAX_STACK, max_depth));
+    Builder b;
+    b.pos = positions;
+    b.out = out;
+    b.leaf_size = leaf_size;
+    b.max_depth = max_depth;
+    b.tb.resize(n_tris);
+    b.cen.resize((size_t)n_tris * 3);
+    b.order.resize(n_tris);
+    Box all;
+    all.reset();
+    for (int i = 0; i < n_tris; ++i) {
+        const float* p = positions + (size_t)i * 9;
+        Box t;
+        t.reset();
+        t.grow(p); t.grow(p + 3); t.grow(p + 6);
+        b.tb[i] = t;
+        for (int a = 0; a < 3; ++a) b.cen[(size_t)i * 3 + a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
+        b.order[i] = i;
+        all.grow(t);
+    }
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::max(ext, all.mx[a] - all.mn[a]);
+        ext = std::max(ext, std::max(std::fabs(all.mn[a]), std::fabs(all.mx[a])));
+    }
+    // Spatial padding: makes the slab test conservative with respect to every hit the Moeller-Trumbore test can
+    // report (its geometric error is orders of magnitude below 1e-5 * extent), so closest-hit is topology-independent.
+    b.pad = ext * 1e-5f;
+    out->pad = b.pad;
+    out->nodes.reserve((size_t)n_tris);
+    out->root = b.build(0, n_tris, 1, false);
+    out->tris.resize(n_tris);
+    for (int i = 0; i < n_tris; ++i) {
+        int id = b.order[i];
+        PtTri& t = out->tris[i];
+        std::memcpy(t.p0, positions + (size_t)id * 9, 36);
+        t.id = id;
+        t.pad[0] = t.pad[1] = 0;
+    }
+}
+
+// ---- host mirror of the kernel traversal (validation of the builder; same arithmetic as pt_kernel.hip) ----
+
+namespace {
+inline float hfma(float a, float b, float c) { return std::fma(a, b, c); }
+inline float hmin(float a, float b) { return (b != b || a < b) ? a : b; }
+inline float hmax(float a, float b) { return (b != b || a > b) ? a : b; }
+struct hv3 { float x, y, z; };
+inline hv3 hsub(hv3 a, hv3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float hdot(hv3 a, hv3 b) { return hfma(a.z, b.z, hfma(a.y, b.y, a.x * b.x)); }
+inline hv3 hcross(hv3 a, hv3 b) { return {hfma(a.y, b.z, -(a.z * b.y)), hfma(a.z, b.x, -(a.x * b.z)), hfma(a.x, b.y, -(a.y * b.x))}; }
+inline bool hbox(const float* mn, const float* mx, hv3 o, hv3 inv, float tmin, float tbest, float* tn_out)
+{
+    float t0x = (mn[0] - o.x) * inv.x, t1x = (mx[0] - o.x) * inv.x;
+    float t0y = (mn[1] - o.y) * inv.y, t1y = (mx[1] - o.y) * inv.y;
+    float t0z = (mn[2] - o.z) * inv.z, t1z = (mx[2] - o.z) * inv.z;
+    float tn = hmax(hmax(hmin(t0x, t1x), hmin(t0y, t1y)), hmax(hmin(t0z, t1z), tmin));
+    float tf = hmin(hmin(hmax(t0x, t1x), hmax(t0y, t1y)), hmin(hmax(t0z, t1z), tbest));
+    *tn_out = tn;
+    return tn <= tf * 1.0000004f;
+}
+} // namespace
+
+bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t_out, float* u_out,
+                             float* v_out, int32_t* prim)
+{
+    hv3 o{org[0], org[1], org[2]}, d{dir[0], dir[1], dir[2]};
+    hv3 inv{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    float bt = tmax, bu = 0.0f, bv = 0.0f;
+    int32_t bid = 0x7fffffff;
+    int32_t stack[PT_MAX_STACK + 8];
+    int sp = 0;
+    int32_t cur = bvh.root;
+    for (;;) {
+        if (cur >= 0) {
+            const PtNode& nd = bvh.nodes[cur];
+            float tl, tr;
+            bool hl = hbox(nd.lmin, nd.lmax, o, inv, tmin, bt, &tl);
+            bool hr = hbox(nd.rmin, nd.rmax, o, inv, tmin, bt, &tr);
+            if (hl && hr) {
+                bool swap = tr < tl;
+                stack[sp++] = swap ? nd.left : nd.right;
+                cur = swap ? nd.right : nd.left;
+                continue;
+            } else if (hl) { cur = nd.left; continue; }
+            else if (hr) { cur = nd.right; continue; }
+        } else if (cur != -1) {
+            uint32_t code = ~(uint32_t)cur;
+            int first = (int)(code >> 3), count = (int)(code & 7u);
+            for (int i = 0; i < count; ++i) {
+                const PtTri& tr = bvh.tris[first + i];
+                hv3 p0{tr.p0[0], tr.p0[1], tr.p0[2]}, p1{tr.p1[0], tr.p1[1], tr.p1[2]}, p2{tr.p2[0], tr.p2[1], tr.p2[2]};
+                hv3 e1 = hsub(p1, p0), e2 = hsub(p2, p0);
+                hv3 pv = hcross(d, e2);
+                float det = hdot(e1, pv);
+                float idet = 1.0f / det;
+                hv3 tv = hsub(o, p0);
+                float u = hdot(tv, pv) * idet;
+                hv3 qv = hcross(tv, e1);
+                float v = hdot(d, qv) * idet;
+                float t = hdot(e2, qv) * idet;
+                if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmin && (t < bt || (t == bt && tr.id < bid))) {
+                    bt = t; bu = u; bv = v; bid = tr.id;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    *t_out = bt; *u_out = bu; *v_out = bv;
+    *prim = bid == 0x7fffffff ? -1 : bid;
+    return bid != 0x7fffffff;
+}

@@ -1,0 +1,24 @@
+// pt_bvh.h -- host BVH2 builder (replaces owlGroupBuildAccel, path_tracer/src/application.cpp:131-140; OptiX's
+// builder is closed source, this one is our own design: binned SAH, child boxes stored in the parent).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "pt_types.h"
+
+struct PtBvh {
+    std::vector<PtNode> nodes;
+    std::vector<PtTri> tris; // leaf order
+    int32_t root = -1;       // child reference of the root (PT_DONE-like -1 for an empty scene)
+    int depth = 0;           // deepest chain of internal nodes (= stack entries the traversal can need)
+    int max_leaf = 0;
+    float pad = 0.0f;
+};
+
+// positions: n_tris*9 floats in global triangle order.  leaf_size 1..7, max_depth <= PT_MAX_STACK.
+void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max_depth, PtBvh* out);
+
+// Host mirror of the kernel's traversal over the product BVH (validation only, never on the render path).
+bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u,
+                             float* v, int32_t* prim);

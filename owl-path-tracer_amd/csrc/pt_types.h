@@ -1,0 +1,74 @@
+// pt_types.h -- HBM data layout shared by the host builder and the HIP kernel (DESIGN.md "data layout").
+#pragma once
+#include <stdint.h>
+
+// One BVH2 node = both children's boxes + both child references: 64 bytes, 64-byte aligned,
+// fetched by one lane as 4 x global_load_dwordx4 (one half cache line).
+// child >= 0: index of an internal node.  child < 0: leaf, ~child = (first_slot << 3) | count (count 1..7).
+struct PtNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PtNode) == 64, "PtNode must be 64 bytes");
+
+// One triangle in LEAF order: the three vertices (the reference's vertex_buffer values, fetched through
+// index_buffer: device.cu:42-61) + its global id (entity order, then face order).  48 bytes = 3 x dwordx4.
+struct PtTri {
+    float p0[3], p1[3], p2[3];
+    int32_t id;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PtTri) == 48, "PtTri must be 48 bytes");
+
+// Shading record per GLOBAL triangle id: the three vertex normals (device.cu:63-73), the material index
+// (entity_data.material_index) and the three texcoords (device.cu:75-94).  64 bytes = 4 x dwordx4.
+// Flattened per triangle instead of the reference's buffer-of-buffers double indirection.
+struct PtShade {
+    float n0[3], n1[3], n2[3];
+    int32_t material;
+    float tc[6];
+};
+static_assert(sizeof(PtShade) == 64, "PtShade must be 64 bytes");
+
+#define PT_MAT_STRIDE 20 // material_data (17 floats) + texture slot + 2 pad: 80 bytes, 16-byte aligned rows
+#define PT_MAX_STACK 64
+
+struct PtTexDesc {
+    const uint32_t* texels;
+    int32_t width, height;
+};
+
+struct PtCounters {
+    unsigned long long samples, rays, nodes, tris, scatters, env_misses, nan_retries;
+};
+
+struct PtKernelParams {
+    const PtNode* nodes;
+    const PtTri* tris;
+    const PtShade* shade;
+    const float* materials; // n_materials * PT_MAT_STRIDE
+    const PtTexDesc* textures;
+    const uint32_t* pixel_ids; // work queue: launch-index pixel ids owned by this context
+    uint32_t* queue_head;      // one counter per launch
+    uint32_t* rng_state;       // per pixel (launch-index order), carried between spp chunks
+    float* accum;              // per pixel * 3, carried between spp chunks
+    float* out_rgb;            // W*H*3, framebuffer order
+    uint32_t* out_rgba8;       // optional
+    PtCounters* counters;      // optional (instrumented build)
+    PtTexDesc env_map;
+    float cam[12];
+    float env_color[3];
+    float env_intensity;
+    int32_t env_use_map, env_use_auto;
+    int32_t root;              // root child reference (leaf if the scene is tiny)
+    int32_t n_tris;
+    int32_t n_materials;
+    uint32_t n_pixels;         // queue length
+    int32_t width, height;
+    int32_t max_samples;       // total spp of the frame (normalisation)
+    int32_t sample_begin, sample_count; // this launch covers [sample_begin, sample_begin + sample_count)
+    int32_t max_depth;
+    int32_t stack_entries;
+};

@@ -1,0 +1,131 @@
+"""CPU-side checks of the product library (no GPU needed): the C-ABI loads and exports every symbol declared in
+include/mi355pt.h, the host BVH builder agrees with brute force, the camera and pixel-shard helpers are right,
+and the render path refuses to run without the GPU (no fallback)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+from owl_path_tracer_amd.pyhost import binding as B
+
+
+def _declared_symbols():
+    src = open(B.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(B.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+    assert sorted(B.EXPORTS) == names
+    assert B.lib().pt_abi_version() == 1
+
+
+def test_create_without_gpu_fails_loudly_or_succeeds_on_gfx950():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present; covered by the gpu suite")
+    with pytest.raises(B.PtError, match="no usable HIP device|gfx950"):
+        B.Context(0)
+
+
+def test_host_only_context_has_no_render_fallback(cube):
+    ctx = B.Context(-1)
+    ctx.upload_scene(cube["entities"], [m for _, m, _ in cube["materials"]], textures=[np.zeros((2, 2), np.uint32)], mesh_textures=[0])
+    cam = B.to_camera_data([2, 1, 2], [0, 0, 0], [0, 1, 0], 50, 8, 8)
+    with pytest.raises(B.PtError, match="no CPU fallback"):
+        ctx.render(cam, 8, 8, 1, 4)
+    with pytest.raises(B.PtError, match="needs the GPU"):
+        ctx.debug_eval("sin", np.zeros(4, np.float32), 1)
+
+
+def test_upload_validation(cube):
+    ctx = B.Context(-1)
+    ents = cube["entities"]
+    mats = [m for _, m, _ in cube["materials"]]
+    bad = dict(ents[0][0], normals=np.zeros((0, 3), np.float32))
+    with pytest.raises(B.PtError, match="no normal"):  # the reference traps here (macros.hpp:5-11)
+        ctx.upload_scene([(bad, 0)], mats)
+    with pytest.raises(B.PtError, match="material index"):
+        ctx.upload_scene([(ents[0][0], 5)], mats)
+    with pytest.raises(B.PtError, match="before pt_upload_scene|NO_SCENE|pt_set_materials"):
+        B.Context(-1).set_materials(mats)
+
+
+def test_camera_matches_oracle_bitwise(orc):
+    for args in (([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, 512, 512), ([4, 2.5, 0], [0, .75, 0], [0, 1, 0], 50, 1920, 1080),
+                 ([2, 1, 2], [0, 0, 0], [0, 1, 0], 50, 256, 256), ([0, 2, 5], [0, .5, 0], [0, 1, 0], 45, 1080, 1440)):
+        a = B.to_camera_data(*args).as_array()
+        b = orc.to_camera_data(*args).as_array()
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("leaf", [1, 4, 7])
+def test_product_bvh_equals_oracle_brute_force(orc, cornell, leaf):
+    ctx = B.Context(-1)
+    ctx.set_option("leaf_size", leaf)
+    ctx.upload_scene(cornell["entities"], [m for _, m, _ in cornell["materials"]])
+    st = ctx.stats()
+    assert st["n_triangles"] == 17974 and 0 < st["bvh_depth"] <= 48
+    S = orc.Scene(cornell["flat"])
+    P = cornell["flat"]["positions"].reshape(-1, 3, 3)
+    rng = np.random.default_rng(17 + leaf)
+    hits = 0
+    for i in range(1500):
+        if i % 3 == 0:
+            t = P[rng.integers(len(P))]
+            o = (rng.dirichlet([1, 1, 1])[:, None] * t).sum(0)
+        else:
+            o = rng.uniform(-1.5, 1.5, 3) + [0, 1, 0]
+        d = rng.normal(size=3)
+        if i % 7 == 0:
+            d[rng.integers(3)] = 0.0
+        d /= np.linalg.norm(d)
+        a = ctx.closest_hit_host(o, d)
+        b = S.intersect(o, d, use_bvh=False)
+        assert a == b
+        hits += a[0]
+    assert hits > 400
+
+
+def test_bvh_depth_cap(orc, procedural, scene_io):
+    # a long sliver strip forces SAH towards deep unbalanced trees; the builder must stay within the cap
+    n = 3000
+    x = np.arange(n + 1, dtype=np.float32) ** 2 * 1e-3
+    v = np.stack([np.stack([x, 0 * x, 0 * x], 1), np.stack([x, 0 * x + 1e-3, 0 * x], 1)], 1).reshape(-1, 3)
+    idx = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(n)], np.int32)
+    m = dict(vertices=v, normals=np.tile(np.float32([0, 0, 1]), (v.shape[0], 1)), texcoords=np.zeros((0, 2), np.float32), indices=idx)
+    ctx = B.Context(-1)
+    ctx.set_option("max_bvh_depth", 14)
+    ctx.set_option("leaf_size", 2)
+    ctx.upload_scene([(m, 0)], [scene_io.MAT_DEFAULT])
+    assert ctx.stats()["bvh_depth"] <= 14
+    flat = scene_io.flatten_scene([(m, 0)], [("a", scene_io.MAT_DEFAULT, "")])
+    S = orc.Scene(flat)
+    rng = np.random.default_rng(2)
+    for _ in range(300):
+        o = np.array([rng.uniform(0, x[-1]), rng.uniform(-1e-3, 2e-3), 1.0])
+        d = np.array([rng.normal() * 0.01, rng.normal() * 0.001, -1.0])
+        d /= np.linalg.norm(d)
+        assert ctx.closest_hit_host(o, d) == S.intersect(o, d, use_bvh=False)
+
+
+@pytest.mark.parametrize("W,H,tile,world", [(64, 48, 16, 2), (100, 37, 16, 3), (1920, 1080, 16, 8), (17, 9, 8, 4), (8, 8, 32, 1)])
+def test_shard_pixels_partition(W, H, tile, world):
+    parts = [B.shard_pixels(W, H, tile, r, world) for r in range(world)]
+    allp = np.concatenate(parts)
+    assert allp.size == W * H and np.array_equal(np.sort(allp), np.arange(W * H, dtype=np.uint32))
+    if world > 1 and W * H >= 64 * world * 4:
+        sizes = np.array([p.size for p in parts], np.float64)
+        assert sizes.max() / sizes.min() < 1.6
+    # the first 64 ids of a shard are one 8x8 screen block (one wave's starting patch)
+    p = parts[0][:64]
+    if W >= 8 and H >= 8:
+        xs, ys = p % W, p // W
+        assert xs.max() - xs.min() == 7 and ys.max() - ys.min() == 7

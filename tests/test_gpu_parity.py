@@ -1,0 +1,371 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Every check goes through the C-ABI (libmi355pt.so) and
+compares with the CPU oracle on the same seeded inputs.
+
+Tolerance: the kernel and the oracle implement one arithmetic contract (IEEE binary32, explicit fma only, correctly
+rounded div/sqrt, deterministic polynomial transcendentals), so the bar is BIT-EXACT equality of the float framebuffer
+-- per-pixel L2 == 0 against the oracle.  (Against the reference's OptiX build nothing can be measured here; see DESIGN.md.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from owl_path_tracer_amd.pyhost import binding as B
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    ctx = B.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bitwise(a, b, what=""):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        bad = np.argwhere(~same)
+        raise AssertionError("%s: %d of %d values differ; first at %s: gpu=%r oracle=%r" % (what, len(bad), same.size, bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+
+
+def _mats(sc):
+    return [m for _, m, _ in sc["materials"]]
+
+
+def _upload(ctx, sc, textures=None, mesh_textures=None, env=None):
+    ctx.upload_scene(sc["entities"], _mats(sc), textures=textures, mesh_textures=mesh_textures, env=env)
+
+
+def _cam(sc, W, H):
+    c = sc["camera"]
+    return B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+
+
+def _ocam(orc, cam):
+    return orc.camera_from_array(cam.as_array())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_deterministic_libm_bitwise(gpu, orc):
+    rng = np.random.default_rng(99)
+    n = 200_000
+    x = rng.uniform(-8, 8, n).astype(np.float32)
+    for fn in ("sin", "cos", "tan"):
+        assert_bitwise(gpu.debug_eval(fn, x, 1)[:, 0], orc.dm(fn, x), fn)
+    x = np.concatenate([rng.uniform(-50, 50, n // 2), rng.standard_cauchy(n // 2) * 100, [0, np.inf, -np.inf, 1e-30]]).astype(np.float32)
+    assert_bitwise(gpu.debug_eval("atan", x, 1)[:, 0], orc.dm("atan", x), "atan")
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    assert_bitwise(gpu.debug_eval("asin", x, 1)[:, 0], orc.dm("asin", x), "asin")
+    x = np.exp(rng.uniform(-30, 30, n)).astype(np.float32)
+    assert_bitwise(gpu.debug_eval("log", x, 1)[:, 0], orc.dm("log", x), "log")
+    x = rng.uniform(-90, 90, n).astype(np.float32)
+    assert_bitwise(gpu.debug_eval("exp", x, 1)[:, 0], orc.dm("exp", x), "exp")
+    xy = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 3, n)], 1).astype(np.float32)
+    xy[:100, 1] = 2.2
+    xy[100:110, 0] = [0, 1, 0.5, 2, 4, 1e-7, 1e-20, 0.25, 0.75, 1e-3]
+    assert_bitwise(gpu.debug_eval("pow", xy, 1)[:, 0], orc.dm("pow", xy[:, 0], xy[:, 1]), "pow")
+    yx = rng.uniform(-3, 3, (n, 2)).astype(np.float32)
+    yx[:50, 1] = 0
+    assert_bitwise(gpu.debug_eval("atan2", yx, 1)[:, 0], orc.dm("atan2", yx[:, 0], yx[:, 1]), "atan2")
+    # division and sqrt must be the correctly rounded IEEE operations on the GPU
+    x = np.exp(rng.uniform(-40, 40, n)).astype(np.float32)
+    y = rng.uniform(-3, 3, n).astype(np.float32)
+    assert_bitwise(gpu.debug_eval("sqrt", x, 1)[:, 0], np.sqrt(x), "sqrt")
+    assert_bitwise(gpu.debug_eval("div", np.stack([x, y], 1), 1)[:, 0], x / y, "div")
+
+
+def test_rng_kat_on_device(gpu, orc):
+    seeds = np.array([[0, 0], [1919, 1079], [1, 0], [0, 1], [255, 255], [7, 11], [4095, 4095]], np.uint32)
+    out = gpu.debug_eval("rng", seeds.view(np.float32), 5)
+    want_state0 = [1576399551, 2688469361, 3231205618, 1569133783, 1606964575]  # SURVEY 8(a6), reference random.hpp
+    assert out[:5, 0].view(np.uint32).tolist() == want_state0
+    assert out[0, 4:5].view(np.uint32)[0] == 595458768 and out[1, 4:5].view(np.uint32)[0] == 1139548942
+    for i, (u, v) in enumerate(seeds):
+        s = orc.rng_init(int(u), int(v))
+        assert out[i, 0:1].view(np.uint32)[0] == s
+        for k in range(3):
+            f, s = orc.rng_next(s)
+            assert out[i, 1 + k] == np.float32(f)
+
+
+def test_frame_math_bitwise(gpu, orc):
+    rng = np.random.default_rng(5)
+    n = rng.normal(size=(2000, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n[0] = [0, 1, 0]
+    n[1] = np.float32(1 / np.sqrt(3))
+    w = rng.normal(size=(2000, 3))
+    inp = np.concatenate([n, w], 1).astype(np.float32)
+    out = gpu.debug_eval("frame", inp, 12)
+    for i in range(0, 2000, 7):
+        t, b = orc.onb(inp[i, :3])
+        l = orc.to_local(t, b, inp[i, :3], inp[i, 3:])
+        g = orc.to_world(t, b, inp[i, :3], l)
+        assert_bitwise(out[i], np.concatenate([t, b, l, g]), "frame %d" % i)
+
+
+def test_sample_disney_bitwise(gpu, orc, scene_io):
+    import json
+
+    rng = np.random.default_rng(1234)
+    mats = [scene_io.material(roughness=1.0), scene_io.material(metallic=1.0, roughness=0.2),
+            scene_io.material(specular_transmission=1.0, roughness=0.0, specular_transmission_roughness=0.01),
+            scene_io.material(metallic=1.0, roughness=0.1, anisotropic=1.0, specular=0.0),
+            scene_io.material(clearcoat=1.0, clearcoat_gloss=0.9, base_color=[0.0272, 0.112622, 0.8]),
+            scene_io.material(clearcoat=1.0, clearcoat_gloss=0.1, sheen=0.8, sheen_tint=0.5, base_color=[0.7, 0.3, 0.2]),
+            scene_io.material(metallic=0.3, clearcoat=0.6, specular_transmission=0.5, specular_transmission_roughness=0.3, roughness=0.4, sheen=0.2),
+            scene_io.material(base_color=[0, 0, 0], roughness=0.75), scene_io.MAT_DEFAULT.copy()]
+    for name in ("car", "cornell-box", "cube", "dragon", "mitsuba"):
+        _, ms = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", name + ".json"))
+        mats += [m for _, m, _ in ms]
+    rows = []
+    for m in mats:
+        for k in range(120):
+            wo = rng.normal(size=3)
+            wo /= np.linalg.norm(wo)
+            if k % 3 == 0:
+                wo[2] = abs(wo[2])
+            if k % 17 == 0:
+                wo = np.array([1.0, 0.0, 1e-4 * (k % 5)])  # grazing
+                wo /= np.linalg.norm(wo)
+            st = np.uint32(rng.integers(0, 2 ** 32))
+            lobe = np.int32([-1, 3, 0, 2][k % 4])
+            rows.append(np.concatenate([m, wo.astype(np.float32), np.array([st]).view(np.float32), np.array([lobe]).view(np.float32)]))
+    inp = np.stack(rows).astype(np.float32)
+    out = gpu.debug_eval("sample_disney", inp, 9)
+    lobes = set()
+    for i in range(inp.shape[0]):
+        r = orc.sample_disney(inp[i, :17], inp[i, 17:20], int(inp[i, 20:21].view(np.uint32)[0]), int(inp[i, 21:22].view(np.int32)[0]))
+        want = np.concatenate([r["f"], r["wi"], [r["pdf"]]]).astype(np.float32)
+        assert_bitwise(out[i, :7], want, "sample_disney row %d" % i)
+        assert int(out[i, 7:8].view(np.int32)[0]) == r["lobe"] and int(out[i, 8:9].view(np.uint32)[0]) == r["state"]
+        lobes.add(r["lobe"])
+    assert lobes == {0, 1, 2, 3}
+
+
+def test_closest_hit_bitwise(gpu, orc, cornell):
+    _upload(gpu, cornell)
+    S = orc.Scene(cornell["flat"])
+    P = cornell["flat"]["positions"].reshape(-1, 3, 3)
+    rng = np.random.default_rng(77)
+    n = 20000
+    o = rng.uniform(-1.5, 1.5, (n, 3)) + [0, 1, 0]
+    k = rng.integers(len(P), size=n // 2)
+    bary = rng.dirichlet([1, 1, 1], n // 2)
+    o[: n // 2] = (bary[:, :, None] * P[k]).sum(1)  # secondary-like origins on surfaces
+    d = rng.normal(size=(n, 3))
+    d[::11, 1] = 0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inp = np.concatenate([o, d], 1).astype(np.float32)
+    out = gpu.debug_eval("closest_hit", inp, 5)
+    hits = 0
+    for i in range(0, n, 5):
+        ok, t, u, v, prim = S.intersect(inp[i, :3], inp[i, 3:], use_bvh=(i % 2 == 0))
+        assert bool(out[i, 0]) == ok
+        if ok:
+            assert_bitwise(out[i, 1:4], np.float32([t, u, v]), "hit %d" % i)
+            assert int(out[i, 4:5].view(np.int32)[0]) == prim
+            hits += 1
+    assert hits > 1500
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# images
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_cube_image_bitwise_c1(gpu, orc, cube, scene_io):
+    """BASELINE config C1 (cube.json, 256x256, 16 spp, depth 4) at full size: textured, sky environment."""
+    tex = scene_io.checker_texture()
+    env = B.make_env(use_auto=True, intensity=1.0)
+    _upload(gpu, cube, textures=[tex], mesh_textures=[0], env=env)
+    W = H = 256
+    cam = _cam(cube, W, H)
+    gpu.set_option("count", 1)
+    rgb, rgba = gpu.render(cam, W, H, 16, 4, want_rgba8=True)
+    st = gpu.stats()
+    gpu.set_option("count", 0)
+    S = orc.Scene(cube["flat"])
+    want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 4, want_rgba8=True, want_counters=True)
+    assert_bitwise(rgb, want, "cube C1 image")
+    np.testing.assert_array_equal(rgba, want8)
+    for k in ("samples", "rays", "scatters", "env_misses", "nan_retries"):
+        assert st[k] == cnt[k], k
+    assert rgb.std() > 0.01
+
+
+def test_cornell_image_bitwise_and_golden(gpu, orc, cornell):
+    from conftest import GOLDEN
+
+    env = B.make_env(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=env)
+    W = H = 48
+    cam = _cam(cornell, W, H)
+    rgb, _ = gpu.render(cam, W, H, 16, 16)
+    assert_bitwise(rgb, np.load(os.path.join(GOLDEN, "cornell_48x48_16spp_d16_oracle.npy")), "cornell golden")
+    W = H = 128
+    cam = _cam(cornell, W, H)
+    gpu.set_option("count", 1)
+    rgb, rgba = gpu.render(cam, W, H, 32, 16, want_rgba8=True)
+    st = gpu.stats()
+    gpu.set_option("count", 0)
+    S = orc.Scene(cornell["flat"])
+    want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 32, 16, want_rgba8=True, want_counters=True)
+    assert_bitwise(rgb, want, "cornell 128x128x32")
+    np.testing.assert_array_equal(rgba, want8)
+    for k in ("samples", "rays", "scatters", "nan_retries"):
+        assert st[k] == cnt[k], k
+    assert st["kernel_ms"] > 0 and st["launches"] == 1
+
+
+def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
+    """All four lobes + sheen + textures + emitter in one small scene (the car.json material set on spheres)."""
+    _, car = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "car.json"))
+    mats = [(n, (m if n != "Ground" else m), "") for n, m, _ in car]
+    meshes = []
+    for i, (name, m, _) in enumerate(mats):
+        if name == "Ground":
+            meshes.append((name, procedural.quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), (0, 1, 0), uv=True)))
+        elif name == "Light":
+            meshes.append((name, procedural.quad((-2, 4, -2), (2, 4, -2), (2, 4, 2), (-2, 4, 2), (0, -1, 0))))
+        else:
+            a = 2 * np.pi * i / len(mats)
+            meshes.append((name, procedural.uv_sphere((2.2 * np.cos(a), 0.5, 2.2 * np.sin(a)), 0.5, nu=24, nv=12)))
+    ents = scene_io.build_entities(meshes, mats)
+    gi = [n for n, _, _ in mats].index("Ground")
+    tex = scene_io.checker_texture(32, 32, 4)
+    flat = scene_io.flatten_scene(ents, mats, {gi: tex})
+    env = dict(use_auto=True, intensity=0.6)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
+    W, H = 96, 64
+    cam = B.to_camera_data([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H)
+    rgb, rgba = gpu.render(cam, W, H, 24, 16, want_rgba8=True)
+    S = orc.Scene(flat)
+    want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(**env), W, H, 24, 16, want_rgba8=True, want_counters=True)
+    assert_bitwise(rgb, want, "material coverage")
+    np.testing.assert_array_equal(rgba, want8)
+    # environment map path (device.cu:23-39,138-139): same scene under a synthetic 8-bit lat-long map
+    yy, xx = np.mgrid[0:16, 0:32]
+    envmap = ((xx * 8) | ((yy * 16) << 8) | (((xx + yy) * 5) << 16) | (0xFF << 24)).astype(np.uint32)
+    gpu.set_environment(B.make_env(use_map=True, intensity=1.0, env_map=envmap))
+    rgb, _ = gpu.render(cam, W, H, 8, 16)
+    want, _, cnt = S.render(_ocam(orc, cam), orc.make_env(use_map=True, intensity=1.0, env_map=envmap), W, H, 8, 16, want_counters=True)
+    assert cnt["env_misses"] > 0
+    assert_bitwise(rgb, want, "environment map")
+
+
+def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
+    env = B.make_env(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=env)
+    W, H = 80, 56
+    cam = _cam(cornell, W, H)
+    full, _ = gpu.render(cam, W, H, 23, 16)
+    # resumable spp chunks carry (rng, accum) per pixel: identical image (RNG stream is sequential per pixel)
+    gpu.set_option("spp_per_launch", 5)
+    chunked, _ = gpu.render(cam, W, H, 23, 16)
+    assert gpu.stats()["launches"] == 5
+    gpu.set_option("spp_per_launch", 0)
+    assert_bitwise(chunked, full, "chunked == single launch")
+    # pixel-tile shards are disjoint: the sum over ranks (what the RCCL reduce computes) is the 1-GPU image bit-for-bit
+    acc = np.zeros_like(full)
+    for r in range(3):
+        gpu.set_pixel_shard(r, 3, 16)
+        part, _ = gpu.render(cam, W, H, 23, 16)
+        own = np.zeros(W * H, bool)
+        own[B.shard_pixels(W, H, 16, r, 3)] = True
+        own = own.reshape(H, W)[::-1]  # framebuffer rows are flipped (device.cu:251)
+        assert not part[~own].any()
+        acc += part
+    gpu.set_pixel_shard(0, 1, 16)
+    assert_bitwise(acc, full, "sum of shards == full")
+    # material hot-swap without BVH rebuild (reset_field, application.cpp:297-304)
+    mats = np.stack(_mats(cornell)).copy()
+    mats[1, 7] = 0.9  # sphere roughness
+    mats[0, 0:3] = [0.9, 0.2, 0.1]
+    gpu.set_materials(mats)
+    swept, _ = gpu.render(cam, W, H, 8, 16)
+    S = orc.Scene(cornell["flat"])
+    S.set_materials(mats)
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 8, 16)
+    assert_bitwise(swept, want, "after pt_set_materials")
+
+
+def test_error_paths(gpu):
+    fresh = B.Context(0)
+    cam = B.to_camera_data([0, 0, 3], [0, 0, 0], [0, 1, 0], 40, 8, 8)
+    with pytest.raises(B.PtError, match="no geometries"):
+        fresh.render(cam, 8, 8, 1, 1)
+    # empty scene renders the environment only
+    fresh.upload_scene([], np.zeros((0, 17), np.float32), env=B.make_env(color=(0.25, 0.5, 1.0), intensity=0.5))
+    rgb, _ = fresh.render(cam, 8, 8, 3, 4)
+    np.testing.assert_allclose(rgb, np.broadcast_to(np.float32([0.125, 0.25, 0.5]), (8, 8, 3)), rtol=1e-6)
+    with pytest.raises(B.PtError):
+        fresh.render(cam, 0, 8, 1, 1)
+    fresh.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties + exact check of a random pixel subset
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _subset_check(gpu_img, S, orc, cam, env, W, H, spp, depth, n_pix, seed):
+    rng = np.random.default_rng(seed)
+    ids = np.sort(rng.choice(W * H, n_pix, replace=False)).astype(np.uint32)
+    sub = np.zeros((H, W, 3), np.float32)
+    S.render(_ocam(orc, cam), env, W, H, spp, depth, pixel_list=ids, out=sub)
+    ys, xs = (H - 1 - ids // W), ids % W
+    assert_bitwise(gpu_img[ys, xs], sub[ys, xs], "pixel subset at full spp")
+
+
+def test_c2_cornell_full_size(gpu, orc, cornell):
+    """BASELINE C2: cornell-box.json, 512x512, 256 spp, depth 16."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    W = H = 512
+    cam = _cam(cornell, W, H)
+    a, a8 = gpu.render(cam, W, H, 256, 16, want_rgba8=True)
+    st = gpu.stats()
+    b, _ = gpu.render(cam, W, H, 256, 16)
+    assert_bitwise(a, b, "run-to-run determinism")
+    gpu.set_option("spp_per_launch", 64)
+    c, _ = gpu.render(cam, W, H, 256, 16)
+    gpu.set_option("spp_per_launch", 0)
+    assert_bitwise(a, c, "chunked == single launch at full size")
+    assert np.isfinite(a).all() and a.min() >= 0
+    S = orc.Scene(cornell["flat"])
+    _subset_check(a, S, orc, cam, orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 256, 16, 1500, 3)
+    print("C2 kernel_ms=%.1f Msamples/s=%.1f vgprs=%d" % (st["kernel_ms"], W * H * 256 / st["kernel_ms"] / 1e3, st["vgprs"]))
+
+
+def test_c4_dragon_standin_full_size(gpu, orc, scene_io, procedural):
+    """BASELINE C4 on the documented stand-in: 1920x1080, 1024 spp, depth 16 (871 400-triangle 'dragon')."""
+    _, mats = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "dragon.json"))
+    meshes = procedural.dragon_standin()
+    ents = scene_io.build_entities(meshes, mats)
+    env = dict(color=(1, 1, 1), intensity=0.0)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
+    W, H = 1920, 1080
+    cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    a, _ = gpu.render(cam, W, H, 1024, 16)
+    st = gpu.stats()
+    assert np.isfinite(a).all()
+    flat = scene_io.flatten_scene(ents, mats)
+    S = orc.Scene(flat)
+    _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 1024, 16, 600, 4)
+    # shards: rank 3 of 8 renders only its tiles, and exactly the full image's values there
+    gpu.set_pixel_shard(3, 8, 16)
+    part, _ = gpu.render(cam, W, H, 1024, 16)
+    gpu.set_pixel_shard(0, 1, 16)
+    own = np.zeros(W * H, bool)
+    own[B.shard_pixels(W, H, 16, 3, 8)] = True
+    own = own.reshape(H, W)[::-1]
+    assert not part[~own].any()
+    assert_bitwise(part[own], a[own], "shard 3/8 == full image on its tiles")
+    print("C4 kernel_ms=%.1f Msamples/s=%.1f" % (st["kernel_ms"], W * H * 1024 / st["kernel_ms"] / 1e3))
