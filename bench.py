@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render hot path on MI355X.
+
+Workload (BASELINE.json metric "Msamples/sec at 1920x1080x1024spp", config C4): dragon.json materials/camera on the
+documented 871 400-triangle stand-in for the missing dragon.obj.scene, 1920x1080, 1024 spp, max depth 16, black
+environment (intensity 0), light from the 'areaLight' quad.  One "step" = one complete frame.
+
+  python bench.py [--gpus N --steps K --warmup W]           # N = 1
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; every rank holds a scene replica and renders the pixel tiles it owns (16x16 tiles dealt
+round-robin; pixels are independent, samples of one pixel are NOT -- the reference threads one RNG stream through all
+samples of a pixel), then ONE RCCL reduce (sum) of the float3 framebuffer to rank 0.  Total work is fixed => "strong".
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W, H, SPP, DEPTH = 1920, 1080, 1024, 16
+TILE = 16
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def build_workload():
+    import ptamd
+
+    ptamd.load()
+    from owl_path_tracer_amd.pyhost import procedural, scene_io
+
+    _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "dragon.json"))
+    meshes = procedural.dragon_standin()
+    ents = scene_io.build_entities(meshes, mats)
+    return scene_io, mats, ents
+
+
+def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
+    # per node 64 B, per triangle test 36 B, per scatter 152 B (+28 B textured), 4 B per env-map miss,
+    # 12 B per framebuffer pixel
+    return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
+
+
+def cpu_baseline(scene_io, mats, ents, cam_arr, target_s=15.0):
+    """Oracle (kind 'port': our CPU restatement; the reference has no CPU path and cannot be built) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    S = orc.Scene(scene_io.flatten_scene(ents, mats))
+    cam = orc.camera_from_array(cam_arr)
+    env = orc.make_env(color=(1, 1, 1), intensity=0.0)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    S.render(cam, env, W, H, 1, DEPTH, threads=cores)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(64, round(target_s / max(t1, 1e-3)))))
+    t0 = time.perf_counter()
+    S.render(cam, env, W, H, spp, DEPTH, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(W * H * spp / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "same scene/camera at %dx%d, %d spp (of %d), depth %d, %.1f s wall; Msamples/s does not depend on spp" % (W, H, spp, SPP, DEPTH, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-launch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene_io, mats, ents = build_workload()  # also loads the package
+    from owl_path_tracer_amd.pyhost import binding as B
+
+    ctx = B.Context(local_rank)
+    ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    ctx.set_pixel_shard(rank, world, TILE)
+    if args.spp_per_launch:
+        ctx.set_option("spp_per_launch", args.spp_per_launch)
+    cam = B.to_camera_data([4.0, 2.5, 0.0], [0.0, 0.75, 0.0], [0.0, 1.0, 0.0], 50.0, W, H)
+
+    dev = torch.device("cuda", local_rank)
+    fb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_device(cam, W, H, SPP, DEPTH, fb.data_ptr(), None, stream)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)  # the one collective: float3 framebuffer over xGMI
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # instrumented pass (untimed): work counters for the algorithmic-bytes figure
+    ctx.set_option("count", 1)
+    ctx.render_device(cam, W, H, SPP, DEPTH, fb.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    cst = ctx.stats()
+    ctx.set_option("count", 0)
+    own_pixels = int(B.shard_pixels(W, H, TILE, rank, world).size)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ctx.stats()["kernel_ms"])  # HIP events recorded on the launch stream around the kernel(s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ctx.stats()
+
+    if rank == 0:
+        launches = max(1, st["launches"])
+        k_ms = float(np.mean(kernel_ms))  # per frame on this rank
+        alg_bytes = algorithmic_bytes(cst, own_pixels)  # this rank's frame
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        samples = W * H * SPP * args.steps
+        out = {
+            "metric": "Msamples/sec at 1920x1080x1024spp",
+            "value": round(samples / elapsed / 1e6, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C4 dragon.json on the 871400-triangle stand-in (dragon.obj.scene is a missing blob), 1920x1080, 1024 spp, "
+                                   "max_path_depth 16, environment intensity 0, areaLight emission 30",
+                       "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer" % (TILE, TILE, world),
+                       "spp_per_launch": args.spp_per_launch or SPP, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
+                       "bvh_depth": int(st["bvh_depth"])},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None,
+                         "kernel": "pt_render_kernel<false>", "kernel_ms_per_launch": round(k_ms / launches, 3), "launches_per_step": launches,
+                         "algorithmic_bytes_per_launch": int(alg_bytes / launches),
+                         "counts_per_frame_rank0": {k: int(cst[k]) for k in ("samples", "rays", "nodes", "tris", "scatters", "env_misses")},
+                         "vgprs": st["vgprs"], "lds_bytes": st["lds_bytes"], "grid": st["grid"], "block": st["block"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_io, mats, ents, cam.as_array())
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
