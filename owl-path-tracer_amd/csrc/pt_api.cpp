@@ -13,11 +13,12 @@
 #include "pt_bvh.h"
 #include "pt_types.h"
 
-extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int grid, size_t lds_bytes, hipStream_t stream, int count);
+extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int variant, int grid, size_t lds_bytes, hipStream_t stream, int count);
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t pt_kernel_attributes(int count, int* vgprs, int* sgprs, int* static_lds, int* max_blocks_per_cu, size_t lds_bytes);
-extern "C" int pt_kernel_block(void);
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int* block, size_t* lds_bytes, int* pixels_per_block,
+                                         int* vgprs, int* max_blocks_per_cu);
+extern "C" int pt_debug_block(void);
 
 namespace {
 
@@ -66,7 +67,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2;
 
     pt_stats stats{};
     int last_launches = 0;
@@ -219,12 +220,6 @@ void fill_params(pt_ctx* c, PtKernelParams& P)
     P.stack_entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
 }
 
-size_t lds_bytes_for(const pt_ctx* c)
-{
-    int entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
-    return (size_t)entries * pt_kernel_block() * 4 + (size_t)c->n_materials * PT_MAT_STRIDE * 4;
-}
-
 } // namespace
 
 extern "C" {
@@ -296,6 +291,10 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
+    else if (k == "kernel") {
+        if (value != 1 && value != 2) return fail(c, PT_E_INVALID, "kernel must be 1 (lane-per-pixel) or 2 (wavefront-scheduled)");
+        c->kernel = (int)value;
+    }
     else return fail(c, PT_E_INVALID, "unknown option '%s'", key);
     return PT_OK;
 }
@@ -443,14 +442,15 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     if (!c || !cam || !d_out_rgb) return PT_E_INVALID;
     if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: the HIP render path is required and there is no CPU fallback");
     if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "no geometries (pt_upload_scene not called)");
-    if (W <= 0 || H <= 0 || max_samples <= 0 || max_depth < 0 || (int64_t)W * H > (int64_t)0x7fffffff)
-        return fail(c, PT_E_INVALID, "bad render size %dx%d spp %d depth %d", W, H, max_samples, max_depth);
+    if (W <= 0 || H <= 0 || max_samples <= 0 || max_depth < 0 || max_depth > 63 || (int64_t)W * H > (int64_t)0x7fffffff)
+        return fail(c, PT_E_INVALID, "bad render size %dx%d spp %d depth %d (depth must be 0..63)", W, H, max_samples, max_depth);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
     int rc = ensure_queue(c, W, H);
     if (rc) return rc;
 
     int S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
+    S = std::min(S, 1 << 19); // the kernel packs the in-launch sample index into 20 bits
     int n_launch = (max_samples + S - 1) / S;
     if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 4))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 4, stream));
@@ -480,13 +480,13 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.max_samples = max_samples;
     P.max_depth = max_depth;
 
-    size_t lds = lds_bytes_for(c);
-    int vg = 0, sg = 0, slds = 0, occ = 0;
-    HIP_TRY(c, pt_kernel_attributes(c->count, &vg, &sg, &slds, &occ, lds));
+    size_t lds = 0;
+    int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ppb = 0;
+    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, &block, &lds, &ppb, &vg, &occ));
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
     int bpc = c->blocks_per_cu > 0 ? std::min(c->blocks_per_cu, occ) : occ;
-    const int block = pt_kernel_block();
-    long want = ((long)c->n_pixels + block - 1) / block;
+    long want = ((long)c->n_pixels + 63) / 64; // never more waves than 64-pixel groups
+    if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
     int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -494,7 +494,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.queue_head = (uint32_t*)c->d_heads.p + l;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
-        HIP_TRY(c, pt_launch_render(&P, grid, lds, stream, c->count));
+        HIP_TRY(c, pt_launch_render(&P, c->kernel, grid, lds, stream, c->count));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;
@@ -609,7 +609,7 @@ int pt_debug_eval(pt_ctx* c, int32_t op, const float* in, int32_t in_stride, flo
     PtKernelParams P;
     fill_params(c, P);
     if (!c->have_scene) { P.root = -1; P.stack_entries = 1; }
-    size_t lds = (size_t)P.stack_entries * pt_kernel_block() * 4;
+    size_t lds = (size_t)P.stack_entries * pt_debug_block() * 4;
     HIP_TRY(c, pt_launch_debug(&P, op, (const float*)c->d_dbg_in.p, in_stride, (float*)c->d_dbg_out.p, out_stride, (long long)n, lds, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_dbg_out.p, (size_t)n * out_stride * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -298,6 +298,27 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     assert_bitwise(swept, want, "after pt_set_materials")
 
 
+def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
+    """option kernel=1 (persistent lane-per-pixel scheduler) must produce the same bits as the default wavefront scheduler."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    W, H = 96, 72
+    cam = _cam(cornell, W, H)
+    a, _ = gpu.render(cam, W, H, 12, 16)
+    gpu.set_option("kernel", 1)
+    try:
+        b, _ = gpu.render(cam, W, H, 12, 16)
+        gpu.set_option("spp_per_launch", 5)
+        c, _ = gpu.render(cam, W, H, 12, 16)
+    finally:
+        gpu.set_option("spp_per_launch", 0)
+        gpu.set_option("kernel", 2)
+    assert_bitwise(a, b, "kernel 1 == kernel 2")
+    assert_bitwise(a, c, "kernel 1 chunked == kernel 2")
+    S = orc.Scene(cornell["flat"])
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 12, 16)
+    assert_bitwise(a, want, "vs oracle")
+
+
 def test_error_paths(gpu):
     fresh = B.Context(0)
     cam = B.to_camera_data([0, 0, 3], [0, 0, 0], [0, 1, 0], 40, 8, 8)
