@@ -16,8 +16,8 @@
 extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int variant, int grid, size_t lds_bytes, hipStream_t stream, int count);
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int* block, size_t* lds_bytes, int* pixels_per_block,
-                                         int* vgprs, int* max_blocks_per_cu);
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
+                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu);
 extern "C" int pt_debug_block(void);
 
 namespace {
@@ -57,7 +57,7 @@ struct pt_ctx {
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out;
+    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_chunk_done, d_ring;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -67,7 +67,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64;
 
     pt_stats stats{};
     int last_launches = 0;
@@ -272,7 +272,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_chunk_done, &c->d_ring};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -291,6 +291,8 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
+    else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
+    else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
     else if (k == "kernel") {
         if (value != 1 && value != 2) return fail(c, PT_E_INVALID, "kernel must be 1 (lane-per-pixel) or 2 (wavefront-scheduled)");
         c->kernel = (int)value;
@@ -442,21 +444,38 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     if (!c || !cam || !d_out_rgb) return PT_E_INVALID;
     if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: the HIP render path is required and there is no CPU fallback");
     if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "no geometries (pt_upload_scene not called)");
-    if (W <= 0 || H <= 0 || max_samples <= 0 || max_depth < 0 || max_depth > 63 || (int64_t)W * H > (int64_t)0x7fffffff)
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || max_samples <= 0 || max_depth < 0 || max_depth > 63 || (int64_t)W * H > (int64_t)0x7fffffff)
         return fail(c, PT_E_INVALID, "bad render size %dx%d spp %d depth %d (depth must be 0..63)", W, H, max_samples, max_depth);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
     int rc = ensure_queue(c, W, H);
     if (rc) return rc;
 
-    int S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
-    S = std::min(S, 1 << 19); // the kernel packs the in-launch sample index into 20 bits
-    int n_launch = (max_samples + S - 1) / S;
+    // kernel 1 (lane-per-pixel): optional spp chunks = separate launches.  kernel 2 (wavefront): ONE persistent launch that
+    // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
+    int S, n_launch, chunk = 0, n_chunks = 1;
+    if (c->kernel == 1) {
+        S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
+        S = std::min(S, 65535);
+        n_launch = (max_samples + S - 1) / S;
+    } else {
+        chunk = std::min(c->spp_per_launch > 0 ? c->spp_per_launch : c->chunk_spp, std::min(max_samples, 65535));
+        n_chunks = (max_samples + chunk - 1) / chunk;
+        if ((uint64_t)c->n_pixels * (uint64_t)n_chunks >= 0xfffffff0ull) return fail(c, PT_E_LIMIT, "too many (pixel, chunk) tickets");
+        S = max_samples;
+        n_launch = 1;
+        if (n_chunks > 255 || c->n_pixels >= (1u << 24)) return fail(c, PT_E_LIMIT, "ring tags need n_chunks <= 255 and < 2^24 pixels (raise chunk_spp)");
+        if ((rc = ensure(c, c->d_chunk_done, (size_t)c->n_pixels * 4))) return rc;
+        if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 + 4))) return rc; // cells + tail counter
+        HIP_TRY(c, hipMemsetAsync(c->d_chunk_done.p, 0, (size_t)c->n_pixels * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4, stream));
+        HIP_TRY(c, hipMemcpyAsync((uint32_t*)c->d_ring.p + c->n_pixels, &c->n_pixels, 4, hipMemcpyHostToDevice, stream));
+    }
     if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 4))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 4, stream));
     HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
     if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
-    if (n_launch > 1) {
+    if (n_launch > 1 || n_chunks > 1) {
         if ((rc = ensure(c, c->d_rng, (size_t)W * H * 4))) return rc;
         if ((rc = ensure(c, c->d_accum, (size_t)W * H * 12))) return rc;
     }
@@ -479,15 +498,37 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.height = H;
     P.max_samples = max_samples;
     P.max_depth = max_depth;
+    P.chunk_done = (uint32_t*)c->d_chunk_done.p;
+    P.ring = (uint32_t*)c->d_ring.p;
+    P.ring_tail = c->d_ring.p ? (uint32_t*)c->d_ring.p + c->n_pixels : nullptr;
+    P.chunk_spp = chunk;
+    P.n_chunks = n_chunks;
+    P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
 
-    size_t lds = 0;
-    int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ppb = 0;
-    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, &block, &lds, &ppb, &vg, &occ));
+    // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
+    // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
+    size_t lds = 0, state_words = 0;
+    int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 192;
+    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+    if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
+        // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
+        long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
+        if (fit < want_ns) {
+            want_ns = (int)std::max(64L, fit);
+            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+        }
+    }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
     int bpc = c->blocks_per_cu > 0 ? std::min(c->blocks_per_cu, occ) : occ;
-    long want = ((long)c->n_pixels + 63) / 64; // never more waves than 64-pixel groups
+    long want = ((long)c->n_pixels + ns - 1) / ns; // never more path slots than pixels: a pixel's chunks are sequential
     if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
     int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
+    if (state_words) {
+        if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
+        P.slot_state = (uint32_t*)c->d_slots.p;
+    }
+    P.ns = ns;
 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     for (int l = 0; l < n_launch; ++l) {
@@ -551,6 +592,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
             HIP_TRY(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
             c->stats.samples = h.samples; c->stats.rays = h.rays; c->stats.nodes = h.nodes; c->stats.tris = h.tris;
             c->stats.scatters = h.scatters; c->stats.env_misses = h.env_misses; c->stats.nan_retries = h.nan_retries;
+            for (int i = 0; i < 24; ++i) c->stats.sched[i] = h.sched[i];
         }
     }
     *out = c->stats;

@@ -4,7 +4,7 @@
 //
 // Two schedulers over the same device functions (DESIGN.md "kernel"):
 //
-//  pt_render_wave_kernel (default, "wavefront-scheduled"): one wave64 per workgroup owns PT_NS path slots in LDS
+//  pt_render_wave_kernel (default, "wavefront-scheduled"): one wave64 per workgroup owns ns path slots
 //    (a slot = one pixel in flight with its RNG stream, accumulators and current ray) plus two slot queues:
 //    rays waiting for traversal and hits waiting for shading.  The wave alternates between
 //      * a TRAVERSAL phase: every lane walks one ray; each step the wave executes either one BVH-node step or one
@@ -27,8 +27,15 @@ using namespace ptd;
 #define PT_BLOCK 256
 #define PT_DONE (-1) // ~0: a leaf reference with count 0 never occurs
 #define PT_WAVE 64
-#define PT_NS 128          // path slots per wave (power of two)
+#ifndef PT_WAVES_PER_EU
+#define PT_WAVES_PER_EU 4
+#endif
+#ifndef PT_NS_DEFAULT
+#define PT_NS_DEFAULT 192  // path slots per wave: >= 64 + 2*63 + 1 so that an empty ray queue implies a full hit or miss batch
+#endif
+#ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 8    // finished lanes that trigger a retire/refill pass
+#endif
 
 namespace {
 
@@ -40,6 +47,7 @@ struct Hit {
 
 struct Counters {
     uint32_t rays = 0, nodes = 0, tris = 0, scat = 0, env = 0, samples = 0, retry = 0;
+    uint32_t sched[24] = {}; // wave-uniform scheduler census (wavefront kernel)
 };
 
 __device__ __forceinline__ float fmin_hw(float a, float b) { return __builtin_fminf(a, b); }
@@ -293,6 +301,78 @@ __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& p
     return true;
 }
 
+// ---- (pixel, spp-chunk) work items of the wavefront kernel ----------------------------------------------------------------
+// The frame is cut into n_chunks chunks of chunk_spp samples per pixel.  A slot renders ONE chunk of a pixel, publishes the
+// pixel's (rng, accum) state and pushes the pixel onto a device-wide FIFO ring of "pixels whose next chunk may start"; then it
+// takes the next ticket.  Ticket t < n_pixels is chunk 0 of queue entry t (always ready); ticket t >= n_pixels is the
+// (t - n_pixels)-th pixel pushed onto the ring.  FIFO order makes all pixels advance at the same pace, so the end of the frame
+// still has ~n_pixels independent work items: with a slot keeping its pixel for all samples, 60 % of the scheduler iterations
+// ran in a wind-down with ~15 busy lanes; with chunk-major static tickets, slots spent 2.4 G polls waiting for predecessors.
+//
+// Cross-wave hand-off (MI355X_MICROARCH.md "Valid forms", sc1 row): the finishing lane stores the state and the chunk count with
+// agent-scope relaxed atomics (write-through sc1 stores), waits vmcnt(0), then takes a ring position and stores the tagged
+// entry (sc1).  The starting lane polls ITS ring cell with an sc1 load and only then issues the sc1 loads of the state (control
+// dependency).  No fence, no spinning: a slot whose cell is not published yet keeps its ticket and polls again in a later pass.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
+__device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& k, uint32_t& c, int& px, int& py, uint32_t& rng,
+                                            v3& color)
+{
+    if (ticket < P.n_pixels) {
+        k = ticket;
+        c = 0;
+    } else {
+        const uint32_t e = ld_agent(P.ring + ticket % P.n_pixels);
+        if ((e >> 24) != ticket / P.n_pixels) return false; // tag = lap of the ring position (>= 1); cells start at 0
+        k = e & 0xffffffu;
+        c = ld_agent(P.chunk_done + k);
+    }
+    const uint32_t pid = P.pixel_ids[k];
+    px = (int)(pid % (uint32_t)P.width);
+    py = (int)(pid / (uint32_t)P.width);
+    if (c == 0) {
+        rng = rng_init((uint32_t)px, (uint32_t)py); // device.cu:226
+        color = vs(0.0f);
+    } else {
+        rng = ld_agent(P.rng_state + pid);
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(P.accum) + 3 * (size_t)pid;
+        color = V(__uint_as_float(ld_agent(a)), __uint_as_float(ld_agent(a + 1)), __uint_as_float(ld_agent(a + 2)));
+    }
+    return true;
+}
+
+__device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
+{
+    const int left = P.max_samples - (int)c * P.chunk_spp;
+    return left < P.chunk_spp ? left : P.chunk_spp;
+}
+
+// The slot finished chunk c of queue entry k: write the framebuffer (device.cu:246-253) or hand the pixel on.
+__device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k, uint32_t c, int px, int py, uint32_t rng, v3 color)
+{
+    if ((int)c + 1 >= P.n_chunks) {
+        v3 out = color * (1.0f / (float)P.max_samples);                          // device.cu:247
+        size_t ofs = (size_t)px + (size_t)P.width * (size_t)(P.height - 1 - py); // device.cu:251
+        P.out_rgb[3 * ofs] = out.x;
+        P.out_rgb[3 * ofs + 1] = out.y;
+        P.out_rgb[3 * ofs + 2] = out.z;
+        if (P.out_rgba8) P.out_rgba8[ofs] = make_rgba(out);
+    } else {
+        const uint32_t pid = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
+        st_agent(P.rng_state + pid, rng);
+        uint32_t* a = reinterpret_cast<uint32_t*>(P.accum) + 3 * (size_t)pid;
+        st_agent(a, __float_as_uint(color.x));
+        st_agent(a + 1, __float_as_uint(color.y));
+        st_agent(a + 2, __float_as_uint(color.z));
+        st_agent(P.chunk_done + k, c + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state has left this CU before the ring entry does
+        const uint32_t pos = atomicAdd(P.ring_tail, 1u);  // starts at n_pixels
+        st_agent(P.ring + pos % P.n_pixels, k | ((pos / P.n_pixels) << 24));
+    }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Counters& cn)
 {
@@ -312,6 +392,8 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
         atomicAdd(&P.counters->scatters, v[4]);
         atomicAdd(&P.counters->env_misses, v[5]);
         atomicAdd(&P.counters->nan_retries, v[6]);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) atomicAdd(&P.counters->sched[k], (unsigned long long)cn.sched[k]);
     }
 }
 
@@ -385,199 +467,300 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(const PtKernelParam
 // =====================================================================================================================
 // v2: wavefront-scheduled megakernel, one wave64 per workgroup (default)
 // =====================================================================================================================
+//
+// Per-wave storage (DESIGN.md "data layout"):
+//   LDS    stack[level][lane]           the traversal stacks
+//          lray[field][slot]            L_DIR* ray direction; L_A* ray origin while the slot waits for / is in traversal,
+//                                       then the hit (u, v, triangle slot) once traversal has retired it
+//          rayq / hitq / missq          ring buffers of slot ids (one byte each)
+//   HBM/L2 gstate[field][slot]          shading-only state of the slot's pixel and path (G_*), touched once per shading pass
+//          gpark[field][lane]           traversal registers of lanes interrupted by a phase switch
+// Keeping only what the traversal loop touches in LDS is what lets 16 waves share a CU's 160 KiB (the kernel is
+// latency-bound: measured time scales with 1/waves-per-CU).
 
-// slot fields (SoA in LDS: field f of slot s at slotf[f * PT_NS + s])
-enum {
-    F_PIX = 0, F_RNG, F_PACK, F_RETRY, F_COLX, F_COLY, F_COLZ, F_THRX, F_THRY, F_THRZ, F_ORGX, F_ORGY, F_ORGZ, F_DIRX, F_DIRY, F_DIRZ,
-    F_HU, F_HV, F_HT, F_NFIELDS
-};
-// F_PACK: bits 0-19 sample index within the launch, 20-25 depth, 26-28 lobe+1, 29 fresh
-#define PT_PACK(s, depth, lobe, fresh) ((uint32_t)(s) | ((uint32_t)(depth) << 20) | ((uint32_t)((lobe) + 1) << 26) | ((uint32_t)(fresh) << 29))
-// park area fields (per lane)
+enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
+enum { G_PIX = 0, G_RNG, G_PACK, G_COLX, G_COLY, G_COLZ, G_THRX, G_THRY, G_THRZ, G_TICKET, G_QK, G_CHUNK, G_NFIELDS };
+// G_PACK: bits 0-15 sample index within the launch, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
+#define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
+#define PT_FRESH 0xffffffffu // G_PIX marker: slot has no (pixel, chunk) running; G_TICKET then holds a ticket it waits on, or PT_FRESH
 enum { K_PSLOT = 0, K_CUR, K_SP, K_BT, K_BU, K_BV, K_BSLOT, K_BID, K_NFIELDS };
 
-static inline int pt_wave_lds_words(int stack_entries) { return stack_entries * PT_WAVE + K_NFIELDS * PT_WAVE + F_NFIELDS * PT_NS + 2 * PT_NS; }
+static inline size_t pt_wave_lds_bytes(int stack_entries, int ns) { return ((size_t)stack_entries * PT_WAVE + (size_t)L_NFIELDS * ns) * 4 + (((size_t)3 * ns + 15) & ~(size_t)15); }
+static inline size_t pt_wave_state_words(int ns) { return (size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE; }
+
+namespace {
+
+struct WaveCtx {
+    uint32_t* lray;   // LDS
+    uint32_t* gstate; // global, this wave's region
+    uint8_t *rayq, *hitq, *missq;
+    int ns;
+    int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
+    bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
+    __device__ __forceinline__ int wrap(int i) const { return i >= ns ? i - ns : i; } // i < 2 * ns
+};
+
+// One shading pass over up to 64 entries of the hit queue (IS_MISS = false) or the miss queue (IS_MISS = true):
+// device.cu:136-214 for the hit/miss, then sample accumulation, next camera ray / next pixel (device.cu:229-254).
+template <bool COUNT, bool IS_MISS>
+__device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, int lane, Counters& cn)
+{
+    const int ns = w.ns;
+    uint32_t* lray = w.lray;
+    uint32_t* gstate = w.gstate;
+#define LF(f, s) lray[(f) * ns + (s)]
+#define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
+#define GF(f, s) gstate[(f) * ns + (s)]
+#define GFF(f, s) __uint_as_float(gstate[(f) * ns + (s)])
+    uint8_t* q = IS_MISS ? w.missq : w.hitq;
+    int& q_head = IS_MISS ? w.miss_head : w.hit_head;
+    int& q_count = IS_MISS ? w.miss_count : w.hit_count;
+    const int n = q_count < PT_WAVE ? q_count : PT_WAVE;
+    const bool mine = lane < n;
+    if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
+    int ps_slot = 0;
+    bool to_ray = false, to_hit = false, to_wait = false, died = false;
+    if (mine) {
+        ps_slot = (int)q[w.wrap(q_head + lane)];
+        uint32_t pid = GF(G_PIX, ps_slot);
+        uint32_t ticket = GF(G_TICKET, ps_slot);
+        const bool running = pid != PT_FRESH;
+        uint32_t qk = running ? GF(G_QK, ps_slot) : 0u, chunk = running ? GF(G_CHUNK, ps_slot) : 0u;
+        uint32_t pack = running ? GF(G_PACK, ps_slot) : 0u;
+        int s = (int)(pack & 0xffffu);
+        PathState ps;
+        ps.rng = 0; ps.org = vs(0.0f); ps.dir = vs(0.0f); ps.throughput = vs(1.0f); ps.depth = 0; ps.lobe = kLobeNone; ps.retries = 0;
+        int px = 0, py = 0;
+        v3 color = vs(0.0f);
+        bool need_gen = !running;
+        bool have_pixel = running;
+        if (running) {
+            ps.rng = GF(G_RNG, ps_slot);
+            ps.throughput = V(GFF(G_THRX, ps_slot), GFF(G_THRY, ps_slot), GFF(G_THRZ, ps_slot));
+            color = V(GFF(G_COLX, ps_slot), GFF(G_COLY, ps_slot), GFF(G_COLZ, ps_slot));
+            px = (int)(pid & 0xffffu); // G_PIX holds x | y << 16
+            py = (int)(pid >> 16);
+            ps.depth = (int)((pack >> 16) & 63u);
+            ps.lobe = (int)((pack >> 22) & 7u) - 1;
+            ps.retries = (int)(pack >> 25);
+            ps.dir = V(LFF(L_DIRX, ps_slot), LFF(L_DIRY, ps_slot), LFF(L_DIRZ, ps_slot));
+            if (COUNT) ++cn.rays;
+            v3 radiance;
+            const int tslot = IS_MISS ? -1 : (int)LF(L_AZ, ps_slot);
+            int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
+            if (r == SR_RETRY) {
+                to_hit = true; // same hit, fresh draws (device.cu:196-201); L_A* still hold the hit
+            } else if (r == SR_END) {
+                color = color + radiance * ps.throughput; // device.cu:217,243
+                if (COUNT) ++cn.samples;
+                ++s;
+                need_gen = true;
+                if (s == chunk_len(P, chunk)) {
+                    finish_chunk(P, qk, chunk, px, py, ps.rng, color);
+                    have_pixel = false;
+                    ticket = PT_FRESH;
+                }
+            } else {
+                to_ray = true;
+            }
+        }
+        if (need_gen) {
+            if (!have_pixel) {
+                if (ticket == PT_FRESH) ticket = atomicAdd(P.queue_head, 1u); // hipcc aggregates this into one atomic per wave
+                if (ticket >= P.n_tickets) {
+                    died = true;
+                } else if (start_chunk(P, ticket, qk, chunk, px, py, ps.rng, color)) {
+                    have_pixel = true;
+                    s = 0;
+                } else {
+                    to_wait = true; // predecessor chunk still running somewhere: keep the ticket, poll again later
+                }
+            }
+            if (have_pixel) {
+                gen_camera_ray(P, px, py, ps);
+                to_ray = true;
+            }
+        }
+        if (!died) {
+            GF(G_TICKET, ps_slot) = ticket;
+            if (to_wait) {
+                GF(G_PIX, ps_slot) = PT_FRESH;
+            } else {
+                GF(G_PIX, ps_slot) = (uint32_t)px | ((uint32_t)py << 16);
+                GF(G_QK, ps_slot) = qk;
+                GF(G_CHUNK, ps_slot) = chunk;
+                GF(G_RNG, ps_slot) = ps.rng;
+                GF(G_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
+                GF(G_COLX, ps_slot) = __float_as_uint(color.x);
+                GF(G_COLY, ps_slot) = __float_as_uint(color.y);
+                GF(G_COLZ, ps_slot) = __float_as_uint(color.z);
+                GF(G_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
+                GF(G_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
+                GF(G_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
+                if (to_ray) {
+                    LF(L_DIRX, ps_slot) = __float_as_uint(ps.dir.x);
+                    LF(L_DIRY, ps_slot) = __float_as_uint(ps.dir.y);
+                    LF(L_DIRZ, ps_slot) = __float_as_uint(ps.dir.z);
+                    LF(L_AX, ps_slot) = __float_as_uint(ps.org.x);
+                    LF(L_AY, ps_slot) = __float_as_uint(ps.org.y);
+                    LF(L_AZ, ps_slot) = __float_as_uint(ps.org.z);
+                }
+            }
+        }
+    }
+    q_head = w.wrap(q_head + n);
+    q_count -= n;
+    const unsigned long long m_ray = __ballot(to_ray), m_hit = __ballot(to_hit), m_wait = __ballot(to_wait), m_dead = __ballot(died);
+    if (to_ray) w.rayq[w.wrap(w.wrap(w.ray_head + w.ray_count) + rank_in(m_ray))] = (uint8_t)ps_slot;
+    if (to_hit) w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_hit))] = (uint8_t)ps_slot;
+    if (to_wait) w.missq[w.wrap(w.wrap(w.miss_head + w.miss_count) + rank_in(m_wait))] = (uint8_t)ps_slot;
+    w.ray_count += popc64(m_ray);
+    w.hit_count += popc64(m_hit);
+    w.miss_count += popc64(m_wait);
+    w.n_dead += popc64(m_dead);
+    if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? 1 : 0; }
+    // a pass that only polled unpublished tickets must not be repeated before the wave has done something else
+    w.miss_blocked = IS_MISS && n > 0 && popc64(m_wait) == n;
+#undef LF
+#undef LFF
+#undef GF
+#undef GFF
+}
+} // namespace
 
 template <bool COUNT>
-__global__ void __launch_bounds__(PT_WAVE) pt_render_wave_kernel(const PtKernelParams P)
+__global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
-    uint32_t* stack = lds + lane;                                     // stack[level * 64]
-    uint32_t* park = lds + P.stack_entries * PT_WAVE + lane;          // park[field * 64]
-    uint32_t* slotf = lds + (P.stack_entries + K_NFIELDS) * PT_WAVE;  // slotf[field * PT_NS + slot]
-    uint32_t* rayq = slotf + F_NFIELDS * PT_NS;
-    uint32_t* hitq = rayq + PT_NS;
+    const int ns = P.ns;
+    uint32_t* stack = lds + lane;                        // stack[level * 64]
+    uint32_t* lray = lds + P.stack_entries * PT_WAVE;    // lray[field * ns + slot]
+    uint32_t* gstate = P.slot_state + (size_t)blockIdx.x * ((size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE);
+    uint32_t* park = gstate + (size_t)G_NFIELDS * ns + lane; // park[field * 64]
+    WaveCtx w;
+    w.lray = lray;
+    w.gstate = gstate;
+    w.ns = ns;
+    w.rayq = reinterpret_cast<uint8_t*>(lray + L_NFIELDS * ns);
+    w.hitq = w.rayq + ns;
+    w.missq = w.hitq + ns;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtTri* __restrict__ tris = P.tris;
 
-#define SF(f, s) slotf[(f) * PT_NS + (s)]
-#define SFF(f, s) __uint_as_float(slotf[(f) * PT_NS + (s)])
+#define LF(f, s) lray[(f) * ns + (s)]
+#define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 
-    // every slot starts "fresh" (needs a pixel) and sits in the hit queue so that the first shading passes start them
-    for (int i = lane; i < PT_NS; i += PT_WAVE) {
-        hitq[i] = (uint32_t)i;
-        SF(F_PACK, i) = PT_PACK(0, 0, kLobeNone, 1);
+    // every slot starts "fresh" (needs a pixel) and sits in the miss queue so that the first shading passes start them
+    for (int i = lane; i < ns; i += PT_WAVE) {
+        w.missq[i] = (uint8_t)i;
+        gstate[G_PIX * ns + i] = PT_FRESH;
+        gstate[G_TICKET * ns + i] = PT_FRESH;
     }
-    park[K_PSLOT * PT_WAVE] = 0xffffffffu;
-    int ray_head = 0, ray_count = 0, hit_head = 0, hit_count = PT_NS, n_dead = 0, n_parked = 0;
+    w.miss_blocked = false;
+    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
+    int n_parked = 0;
     Counters cn;
 
-    while (n_dead < PT_NS) {
-        const bool do_shade = hit_count >= PT_WAVE || (hit_count > 0 && ray_count == 0 && n_parked == 0);
-        if (do_shade) {
-            // ======================= SHADING PHASE: up to 64 queued hits =======================================
-            const int n = hit_count < PT_WAVE ? hit_count : PT_WAVE;
-            const bool mine = lane < n;
-            int ps_slot = 0;
-            bool to_ray = false, to_hit = false, died = false;
-            if (mine) {
-                ps_slot = (int)hitq[(hit_head + lane) & (PT_NS - 1)];
-                uint32_t pack = SF(F_PACK, ps_slot);
-                bool fresh = (pack >> 29) & 1u;
-                int s = (int)(pack & 0xfffffu);
-                PathState ps;
-                uint32_t pid = 0;
-                int px = 0, py = 0;
-                v3 color = vs(0.0f);
-                bool need_gen = fresh;
-                bool have_pixel = !fresh;
-                if (!fresh) {
-                    pid = SF(F_PIX, ps_slot);
-                    px = (int)(pid % (uint32_t)P.width);
-                    py = (int)(pid / (uint32_t)P.width);
-                    ps.rng = SF(F_RNG, ps_slot);
-                    ps.depth = (int)((pack >> 20) & 63u);
-                    ps.lobe = (int)((pack >> 26) & 7u) - 1;
-                    ps.retries = (int)SF(F_RETRY, ps_slot);
-                    ps.throughput = V(SFF(F_THRX, ps_slot), SFF(F_THRY, ps_slot), SFF(F_THRZ, ps_slot));
-                    ps.org = V(SFF(F_ORGX, ps_slot), SFF(F_ORGY, ps_slot), SFF(F_ORGZ, ps_slot));
-                    ps.dir = V(SFF(F_DIRX, ps_slot), SFF(F_DIRY, ps_slot), SFF(F_DIRZ, ps_slot));
-                    color = V(SFF(F_COLX, ps_slot), SFF(F_COLY, ps_slot), SFF(F_COLZ, ps_slot));
-                    if (COUNT) ++cn.rays;
-                    v3 radiance;
-                    int r = shade_hit<COUNT>(P, P.materials, (int)SF(F_HT, ps_slot), SFF(F_HU, ps_slot), SFF(F_HV, ps_slot), ps, radiance, cn);
-                    if (r == SR_RETRY) {
-                        to_hit = true; // same hit, fresh draws (device.cu:196-201)
-                    } else if (r == SR_END) {
-                        color = color + radiance * ps.throughput; // device.cu:217,243
-                        if (COUNT) ++cn.samples;
-                        ++s;
-                        need_gen = true;
-                        if (s == P.sample_count) {
-                            finish_pixel(P, pid, px, py, ps.rng, color);
-                            have_pixel = false;
-                        }
-                    } else {
-                        to_ray = true;
-                    }
-                }
-                if (need_gen) {
-                    if (!have_pixel) {
-                        have_pixel = fetch_pixel(P, pid, px, py, ps.rng, color);
-                        s = 0;
-                    }
-                    if (have_pixel) {
-                        gen_camera_ray(P, px, py, ps);
-                        to_ray = true;
-                    } else {
-                        died = true;
-                    }
-                }
-                if (!died) {
-                    SF(F_PIX, ps_slot) = pid;
-                    SF(F_RNG, ps_slot) = ps.rng;
-                    SF(F_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, 0);
-                    SF(F_RETRY, ps_slot) = (uint32_t)ps.retries;
-                    SF(F_COLX, ps_slot) = __float_as_uint(color.x);
-                    SF(F_COLY, ps_slot) = __float_as_uint(color.y);
-                    SF(F_COLZ, ps_slot) = __float_as_uint(color.z);
-                    SF(F_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
-                    SF(F_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
-                    SF(F_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
-                    SF(F_ORGX, ps_slot) = __float_as_uint(ps.org.x);
-                    SF(F_ORGY, ps_slot) = __float_as_uint(ps.org.y);
-                    SF(F_ORGZ, ps_slot) = __float_as_uint(ps.org.z);
-                    SF(F_DIRX, ps_slot) = __float_as_uint(ps.dir.x);
-                    SF(F_DIRY, ps_slot) = __float_as_uint(ps.dir.y);
-                    SF(F_DIRZ, ps_slot) = __float_as_uint(ps.dir.z);
-                }
-            }
-            hit_head = (hit_head + n) & (PT_NS - 1);
-            hit_count -= n;
-            const unsigned long long m_ray = __ballot(to_ray), m_hit = __ballot(to_hit), m_dead = __ballot(died);
-            if (to_ray) rayq[(ray_head + ray_count + rank_in(m_ray)) & (PT_NS - 1)] = (uint32_t)ps_slot;
-            if (to_hit) hitq[(hit_head + hit_count + rank_in(m_hit)) & (PT_NS - 1)] = (uint32_t)ps_slot;
-            ray_count += popc64(m_ray);
-            hit_count += popc64(m_hit);
-            n_dead += popc64(m_dead);
+    while (w.n_dead < ns) {
+        const bool starving = w.ray_count == 0 && n_parked == 0; // traversal has nothing to do: shade whatever is queued
+        if (w.hit_count >= PT_WAVE || (starving && w.hit_count > 0 && (w.hit_count >= w.miss_count || w.miss_blocked))) {
+            shade_pass<COUNT, false>(P, w, lane, cn);
+        } else if (!w.miss_blocked && (w.miss_count >= PT_WAVE || (starving && w.miss_count > 0))) {
+            shade_pass<COUNT, true>(P, w, lane, cn);
+        } else if (starving && w.hit_count == 0) {
+            // every live slot of this wave waits for a chunk that another wave is still rendering
+            __builtin_amdgcn_s_sleep(64);
+            w.miss_blocked = false;
+            if (COUNT) cn.sched[18] += 1;
         } else {
             // ======================= TRAVERSAL PHASE ==============================================================
-            int pslot = (int)park[K_PSLOT * PT_WAVE];
+            int pslot = -1;
             int cur = PT_DONE, sp = 0;
             Hit h;
             h.t = kTMax; h.u = h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
             v3 o = vs(0.0f), d = vs(1.0f), inv = vs(1.0f);
-            if (pslot >= 0) { // resume a traversal parked by the previous phase switch
-                cur = (int)park[K_CUR * PT_WAVE];
-                sp = (int)park[K_SP * PT_WAVE];
-                h.t = __uint_as_float(park[K_BT * PT_WAVE]);
-                h.u = __uint_as_float(park[K_BU * PT_WAVE]);
-                h.v = __uint_as_float(park[K_BV * PT_WAVE]);
-                h.slot = (int)park[K_BSLOT * PT_WAVE];
-                h.id = (int)park[K_BID * PT_WAVE];
-                o = V(SFF(F_ORGX, pslot), SFF(F_ORGY, pslot), SFF(F_ORGZ, pslot));
-                d = V(SFF(F_DIRX, pslot), SFF(F_DIRY, pslot), SFF(F_DIRZ, pslot));
-                inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            if (n_parked > 0) { // resume traversals parked by the previous phase switch
+                pslot = (int)park[K_PSLOT * PT_WAVE];
+                if (pslot >= 0) {
+                    cur = (int)park[K_CUR * PT_WAVE];
+                    sp = (int)park[K_SP * PT_WAVE];
+                    h.t = __uint_as_float(park[K_BT * PT_WAVE]);
+                    h.u = __uint_as_float(park[K_BU * PT_WAVE]);
+                    h.v = __uint_as_float(park[K_BV * PT_WAVE]);
+                    h.slot = (int)park[K_BSLOT * PT_WAVE];
+                    h.id = (int)park[K_BID * PT_WAVE];
+                    o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
+                    d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
+                    inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                }
             }
             bool first = true;
+            int n_retire_passes = 0;
             for (;;) {
-                const unsigned long long m_done = __ballot(pslot >= 0 && cur == PT_DONE);
-                const unsigned long long m_node = __ballot(pslot >= 0 && cur >= 0);
-                const unsigned long long m_leaf = __ballot(pslot >= 0 && cur < PT_DONE);
+                // idle lanes (pslot < 0) always hold cur == PT_DONE
+                const unsigned long long m_done = __ballot(cur == PT_DONE && pslot >= 0);
+                const unsigned long long m_node = __ballot(cur >= 0);
+                const unsigned long long m_leaf = __ballot(cur < PT_DONE);
                 const int n_done = popc64(m_done);
+                if (COUNT) {
+                    const int n_idle_c = popc64(__ballot(pslot < 0));
+                    cn.sched[12] += 1; cn.sched[13] += n_idle_c; cn.sched[14] += n_done; cn.sched[15] += popc64(m_node | m_leaf);
+                    if (w.n_dead > 0) { cn.sched[10] += 1; cn.sched[11] += n_idle_c; } // wind-down: the pixel queue is exhausted
+                }
                 if (first || n_done >= PT_RETIRE_MIN || (m_node | m_leaf) == 0ull) {
                     first = false;
-                    // ---- retire finished rays into the hit queue ----
-                    if (pslot >= 0 && cur == PT_DONE) {
-                        SF(F_HU, pslot) = __float_as_uint(h.u);
-                        SF(F_HV, pslot) = __float_as_uint(h.v);
-                        SF(F_HT, pslot) = (uint32_t)h.slot;
-                        hitq[(hit_head + hit_count + rank_in(m_done)) & (PT_NS - 1)] = (uint32_t)pslot;
-                        pslot = -1;
+                    // ---- retire finished rays into the hit / miss queues (the hit overwrites the ray origin) ----
+                    const bool fin = pslot >= 0 && cur == PT_DONE;
+                    const bool fin_hit = fin && h.slot >= 0;
+                    const bool fin_miss = fin && h.slot < 0;
+                    const unsigned long long m_fh = __ballot(fin_hit), m_fm = __ballot(fin_miss);
+                    if (COUNT) { cn.sched[4] += 1; cn.sched[5] += popc64(m_fh | m_fm); }
+                    if (fin_hit) {
+                        LF(L_AX, pslot) = __float_as_uint(h.u);
+                        LF(L_AY, pslot) = __float_as_uint(h.v);
+                        LF(L_AZ, pslot) = (uint32_t)h.slot;
+                        w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_fh))] = (uint8_t)pslot;
                     }
-                    hit_count += n_done;
+                    if (fin_miss) w.missq[w.wrap(w.wrap(w.miss_head + w.miss_count) + rank_in(m_fm))] = (uint8_t)pslot;
+                    if (fin) pslot = -1;
+                    w.hit_count += popc64(m_fh);
+                    w.miss_count += popc64(m_fm);
                     // ---- refill idle lanes from the ray queue ----
                     const unsigned long long m_idle = __ballot(pslot < 0);
                     const int n_idle = popc64(m_idle);
-                    const int take = n_idle < ray_count ? n_idle : ray_count;
+                    const int take = n_idle < w.ray_count ? n_idle : w.ray_count;
                     if (take > 0) {
                         const int rk = rank_in(m_idle);
                         if (pslot < 0 && rk < take) {
-                            pslot = (int)rayq[(ray_head + rk) & (PT_NS - 1)];
-                            o = V(SFF(F_ORGX, pslot), SFF(F_ORGY, pslot), SFF(F_ORGZ, pslot));
-                            d = V(SFF(F_DIRX, pslot), SFF(F_DIRY, pslot), SFF(F_DIRZ, pslot));
+                            pslot = (int)w.rayq[w.wrap(w.ray_head + rk)];
+                            o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
+                            d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
                             inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                             cur = P.root;
                             sp = 0;
                             h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
                         }
-                        ray_head = (ray_head + take) & (PT_NS - 1);
-                        ray_count -= take;
+                        w.ray_head = w.wrap(w.ray_head + take);
+                        w.ray_count -= take;
                     }
                     const unsigned long long m_busy = __ballot(pslot >= 0);
-                    if (m_busy == 0ull) break;                           // nothing in flight (the ray queue is empty too)
-                    if (ray_count == 0 && hit_count >= PT_WAVE) break;   // a full shading batch is waiting and no ray is queued
+                    if (m_busy == 0ull) break;                                                           // nothing in flight
+                    if (++n_retire_passes >= 16) w.miss_blocked = false; // time to poll the waiting tickets again
+                    // a full shading batch is ready: go and turn it into rays (a miss queue that only holds unpublished tickets does not count)
+                    if (w.hit_count >= PT_WAVE || (!w.miss_blocked && w.miss_count >= PT_WAVE)) break;
                     continue;
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test ----
                 if (popc64(m_node) >= popc64(m_leaf)) {
-                    if (pslot >= 0 && cur >= 0) {
+                    if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
+                    if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
                         node_step<PT_WAVE>(nodes, stack, o, inv, h.t, cur, sp);
                     }
                 } else {
-                    if (pslot >= 0 && cur < PT_DONE) {
+                    if (COUNT) { cn.sched[2] += 1; cn.sched[3] += popc64(m_leaf); }
+                    if (cur < PT_DONE) {
                         uint32_t code = ~(uint32_t)cur;
                         int firstt = (int)(code >> 3), count = (int)(code & 7u);
                         if (COUNT) ++cn.tris;
@@ -594,21 +777,23 @@ __global__ void __launch_bounds__(PT_WAVE) pt_render_wave_kernel(const PtKernelP
                 }
             }
             // ---- park unfinished traversals until the next traversal phase ----
-            park[K_PSLOT * PT_WAVE] = (uint32_t)pslot;
-            if (pslot >= 0) {
-                park[K_CUR * PT_WAVE] = (uint32_t)cur;
-                park[K_SP * PT_WAVE] = (uint32_t)sp;
-                park[K_BT * PT_WAVE] = __float_as_uint(h.t);
-                park[K_BU * PT_WAVE] = __float_as_uint(h.u);
-                park[K_BV * PT_WAVE] = __float_as_uint(h.v);
-                park[K_BSLOT * PT_WAVE] = (uint32_t)h.slot;
-                park[K_BID * PT_WAVE] = (uint32_t)h.id;
-            }
             n_parked = popc64(__ballot(pslot >= 0));
+            if (n_parked > 0) {
+                park[K_PSLOT * PT_WAVE] = (uint32_t)pslot;
+                if (pslot >= 0) {
+                    park[K_CUR * PT_WAVE] = (uint32_t)cur;
+                    park[K_SP * PT_WAVE] = (uint32_t)sp;
+                    park[K_BT * PT_WAVE] = __float_as_uint(h.t);
+                    park[K_BU * PT_WAVE] = __float_as_uint(h.u);
+                    park[K_BV * PT_WAVE] = __float_as_uint(h.v);
+                    park[K_BSLOT * PT_WAVE] = (uint32_t)h.slot;
+                    park[K_BID * PT_WAVE] = (uint32_t)h.id;
+                }
+            }
         }
     }
-#undef SF
-#undef SFF
+#undef LF
+#undef LFF
     flush_counters<COUNT>(P, cn);
 }
 
@@ -705,21 +890,25 @@ extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const flo
     return hipGetLastError();
 }
 
-// Launch geometry of a render variant: block size, dynamic LDS bytes, pixels a block keeps in flight, registers, occupancy.
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int* block, size_t* lds_bytes, int* pixels_per_block,
-                                         int* vgprs, int* max_blocks_per_cu)
+// Launch geometry of a render variant: block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for
+// the wavefront kernel), per-block global state words, registers, occupancy.
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
+                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu)
 {
     const void* fn;
     if (variant == 1) {
         fn = count ? (const void*)pt_render_kernel<true> : (const void*)pt_render_kernel<false>;
         *block = PT_BLOCK;
         *lds_bytes = (size_t)stack_entries * PT_BLOCK * 4;
-        *pixels_per_block = PT_BLOCK;
+        *ns = PT_BLOCK;
+        *state_words_per_block = 0;
     } else {
         fn = count ? (const void*)pt_render_wave_kernel<true> : (const void*)pt_render_wave_kernel<false>;
+        int n = want_ns < PT_WAVE ? PT_WAVE : (want_ns > 255 ? 255 : want_ns);
         *block = PT_WAVE;
-        *lds_bytes = (size_t)pt_wave_lds_words(stack_entries) * 4;
-        *pixels_per_block = PT_NS;
+        *ns = n;
+        *lds_bytes = pt_wave_lds_bytes(stack_entries, n);
+        *state_words_per_block = pt_wave_state_words(n);
     }
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, fn);

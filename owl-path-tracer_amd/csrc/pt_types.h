@@ -42,6 +42,8 @@ struct PtTexDesc {
 
 struct PtCounters {
     unsigned long long samples, rays, nodes, tris, scatters, env_misses, nan_retries;
+    // scheduler census of the wavefront kernel (wave-level events and the lanes that took part in them)
+    unsigned long long sched[24];
 };
 
 struct PtKernelParams {
@@ -57,6 +59,10 @@ struct PtKernelParams {
     float* out_rgb;            // W*H*3, framebuffer order
     uint32_t* out_rgba8;       // optional
     PtCounters* counters;      // optional (instrumented build)
+    uint32_t* slot_state;      // wavefront kernel: per-wave path-slot state + park area (pt_wave_state_words each)
+    uint32_t* chunk_done;      // wavefront kernel: per queue entry, number of published spp chunks
+    uint32_t* ring;            // wavefront kernel: FIFO of queue entries whose next chunk may start (n_pixels cells, lap-tagged)
+    uint32_t* ring_tail;       // next ring position (starts at n_pixels)
     PtTexDesc env_map;
     float cam[12];
     float env_color[3];
@@ -71,4 +77,7 @@ struct PtKernelParams {
     int32_t sample_begin, sample_count; // this launch covers [sample_begin, sample_begin + sample_count)
     int32_t max_depth;
     int32_t stack_entries;
+    int32_t ns;                // wavefront kernel: path slots per wave (64..255)
+    int32_t chunk_spp, n_chunks; // wavefront kernel: samples per (pixel, chunk) ticket and chunks per pixel
+    uint32_t n_tickets;        // n_pixels * n_chunks
 };

@@ -271,7 +271,7 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     # resumable spp chunks carry (rng, accum) per pixel: identical image (RNG stream is sequential per pixel)
     gpu.set_option("spp_per_launch", 5)
     chunked, _ = gpu.render(cam, W, H, 23, 16)
-    assert gpu.stats()["launches"] == 5
+    assert gpu.stats()["launches"] == 1  # the wavefront kernel walks its (pixel, chunk) tickets inside one persistent launch
     gpu.set_option("spp_per_launch", 0)
     assert_bitwise(chunked, full, "chunked == single launch")
     # pixel-tile shards are disjoint: the sum over ranks (what the RCCL reduce computes) is the 1-GPU image bit-for-bit

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""A/B timing of libmi355pt.so variants on one GPU: PT_LIB_PATH=<.so> python tools/ab_bench.py [c4|c2] [reps] [opt=val ...]"""
+import os, sys, json, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import ptamd
+ptamd.load()
+from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "c4"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    opts = dict(a.split("=") for a in sys.argv[3:])
+    ctx = B.Context(0)
+    for k, v in opts.items():
+        if k in ("leaf_size", "max_bvh_depth"):
+            ctx.set_option(k, int(v))
+    if which == "c4":
+        _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "dragon.json"))
+        ents = scene_io.build_entities(procedural.dragon_standin(), mats)
+        W, H, spp = 1920, 1080, int(opts.get("spp", 1024))
+        cam = B.to_camera_data([4, 2.5, 0], [0, .75, 0], [0, 1, 0], 50, W, H)
+    else:
+        sc = scene_io.load_scene_dir(os.path.join(ROOT, "assets"), "cornell-box")
+        mats, ents = sc["materials"], sc["entities"]
+        W, H, spp = 512, 512, int(opts.get("spp", 256))
+        c = sc["camera"]
+        cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+    ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    for k, v in opts.items():
+        if k not in ("leaf_size", "max_bvh_depth", "spp", "census"):
+            ctx.set_option(k, int(v))
+    ms = []
+    for _ in range(reps):
+        ctx.render(cam, W, H, spp, 16)
+        ms.append(ctx.stats()["kernel_ms"])
+    st = ctx.stats()
+    if opts.get("census"):
+        ctx.set_option("count", 1)
+        ctx.render(cam, W, H, spp, 16)
+        cs = ctx.stats()
+        ctx.set_option("count", 0)
+        sc = cs["sched"]
+        names = ["node_steps", "node_lanes", "tri_steps", "tri_lanes", "retire_passes", "retired", "hit_passes", "hit_items", "miss_passes", "miss_items", "winddown_iters", "winddown_idle", "iters", "idle_sum", "donewait_sum", "active_sum", "wait_polls", "passes_after_death", "sleeps"]
+        cen = dict(zip(names, sc))
+        cen.update({k: cs[k] for k in ("rays", "nodes", "tris", "scatters", "samples")})
+        for a, b in (("node_lanes", "node_steps"), ("tri_lanes", "tri_steps"), ("retired", "retire_passes"), ("hit_items", "hit_passes"), ("miss_items", "miss_passes"), ("winddown_idle", "winddown_iters"), ("idle_sum", "iters"), ("donewait_sum", "iters"), ("active_sum", "iters")):
+            cen[a + "/" + b] = round(cen[a] / max(1, cen[b]), 2)
+        print(json.dumps(cen))
+    print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
+                      "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
+                      "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"]}))
+
+main()
