@@ -25,7 +25,6 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 W, H, SPP, DEPTH = 1920, 1080, 1024, 16
-TILE = 16
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -47,6 +46,18 @@ def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
     return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
 
 
+def effective_cpus():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives 16 of 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(scene_io, mats, ents, cam_arr, target_s=15.0):
     """Oracle (kind 'port': our CPU restatement; the reference has no CPU path and cannot be built) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -55,7 +66,7 @@ def cpu_baseline(scene_io, mats, ents, cam_arr, target_s=15.0):
     S = orc.Scene(scene_io.flatten_scene(ents, mats))
     cam = orc.camera_from_array(cam_arr)
     env = orc.make_env(color=(1, 1, 1), intensity=0.0)
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     t0 = time.perf_counter()
     S.render(cam, env, W, H, 1, DEPTH, threads=cores)
     t1 = time.perf_counter() - t0
@@ -64,7 +75,8 @@ def cpu_baseline(scene_io, mats, ents, cam_arr, target_s=15.0):
     S.render(cam, env, W, H, spp, DEPTH, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(W * H * spp / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "same scene/camera at %dx%d, %d spp (of %d), depth %d, %.1f s wall; Msamples/s does not depend on spp" % (W, H, spp, SPP, DEPTH, dt)}
+            "sample": "same scene/camera at %dx%d, %d spp (of %d), depth %d, %.1f s wall, %d threads; Msamples/s does not depend on spp"
+                      % (W, H, spp, SPP, DEPTH, dt, cores)}
 
 
 def main():
@@ -79,9 +91,12 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import ptamd
+
+    ptamd.load()
+    from owl_path_tracer_amd.pyhost import distributed as D
+
+    rank, local_rank, world = D.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
@@ -89,16 +104,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    D.init(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     scene_io, mats, ents = build_workload()  # also loads the package
     from owl_path_tracer_amd.pyhost import binding as B
 
     ctx = B.Context(local_rank)
     ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
-    ctx.set_pixel_shard(rank, world, TILE)
+    ctx.set_pixel_shard(rank, world, D.TILE)
     if args.spp_per_launch:
         ctx.set_option("spp_per_launch", args.spp_per_launch)
     cam = B.to_camera_data([4.0, 2.5, 0.0], [0.0, 0.75, 0.0], [0.0, 1.0, 0.0], 50.0, W, H)
@@ -109,8 +122,7 @@ def main():
 
     def step():
         ctx.render_device(cam, W, H, SPP, DEPTH, fb.data_ptr(), None, stream)
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)  # the one collective: float3 framebuffer over xGMI
+        D.reduce_framebuffer(fb, dst=0)  # the one collective: float3 framebuffer over xGMI (no-op for one rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,7 +136,7 @@ def main():
     torch.cuda.synchronize()
     cst = ctx.stats()
     ctx.set_option("count", 0)
-    own_pixels = int(B.shard_pixels(W, H, TILE, rank, world).size)
+    own_pixels = int(B.shard_pixels(W, H, D.TILE, rank, world).size)
 
     for _ in range(args.warmup):
         step()
@@ -163,12 +175,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C4 dragon.json on the 871400-triangle stand-in (dragon.obj.scene is a missing blob), 1920x1080, 1024 spp, "
                                    "max_path_depth 16, environment intensity 0, areaLight emission 30",
-                       "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer" % (TILE, TILE, world),
-                       "spp_per_launch": args.spp_per_launch or SPP, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
+                       "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer" % (D.TILE, D.TILE, world),
+                       "kernel": "wavefront-scheduled megakernel, one persistent launch per frame", "chunk_spp": args.spp_per_launch or 64, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
                        "bvh_depth": int(st["bvh_depth"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None,
-                         "kernel": "pt_render_kernel<false>", "kernel_ms_per_launch": round(k_ms / launches, 3), "launches_per_step": launches,
+                         "kernel": "pt_render_wave_kernel<false>", "kernel_ms_per_launch": round(k_ms / launches, 3), "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": int(alg_bytes / launches),
                          "counts_per_frame_rank0": {k: int(cst[k]) for k in ("samples", "rays", "nodes", "tris", "scatters", "env_misses")},
                          "vgprs": st["vgprs"], "lds_bytes": st["lds_bytes"], "grid": st["grid"], "block": st["block"]},

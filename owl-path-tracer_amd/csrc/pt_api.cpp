@@ -509,7 +509,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 192;
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 160; // measured best on C4 (128..255 swept, profiles/r01_sweeps.md)
     HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
         // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)

@@ -34,7 +34,7 @@ using namespace ptd;
 #define PT_NS_DEFAULT 192  // path slots per wave: >= 64 + 2*63 + 1 so that an empty ray queue implies a full hit or miss batch
 #endif
 #ifndef PT_RETIRE_MIN
-#define PT_RETIRE_MIN 8    // finished lanes that trigger a retire/refill pass
+#define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
 
 namespace {
