@@ -87,7 +87,7 @@ typedef struct pt_stats {
     /* counted renders, wavefront kernel: {node steps, lanes in them, triangle steps, lanes, retire passes, lanes retired,
      * hit-shading passes, items, miss-shading passes, items, traversal phases, parked lanes,
      * scheduler iterations, sum of idle lanes, sum of finished lanes awaiting retirement, sum of node+leaf lanes} */
-    uint64_t sched[24];
+    uint64_t sched[32];
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */

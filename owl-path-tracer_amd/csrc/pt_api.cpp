@@ -592,7 +592,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
             HIP_TRY(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
             c->stats.samples = h.samples; c->stats.rays = h.rays; c->stats.nodes = h.nodes; c->stats.tris = h.tris;
             c->stats.scatters = h.scatters; c->stats.env_misses = h.env_misses; c->stats.nan_retries = h.nan_retries;
-            for (int i = 0; i < 24; ++i) c->stats.sched[i] = h.sched[i];
+            for (int i = 0; i < 32; ++i) c->stats.sched[i] = h.sched[i];
         }
     }
     *out = c->stats;

@@ -47,7 +47,8 @@ struct Hit {
 
 struct Counters {
     uint32_t rays = 0, nodes = 0, tris = 0, scat = 0, env = 0, samples = 0, retry = 0;
-    uint32_t sched[24] = {}; // wave-uniform scheduler census (wavefront kernel)
+    unsigned long long cyc[8] = {}; // COUNT build: shader-clock cycles per phase {node steps, tri steps, retire, hit pass, miss pass, park/resume, sleep, total}
+    uint32_t sched[32] = {}; // wave-uniform scheduler census (wavefront kernel)
 };
 
 __device__ __forceinline__ float fmin_hw(float a, float b) { return __builtin_fminf(a, b); }
@@ -394,6 +395,8 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
         atomicAdd(&P.counters->nan_retries, v[6]);
 #pragma unroll
         for (int k = 0; k < 24; ++k) atomicAdd(&P.counters->sched[k], (unsigned long long)cn.sched[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&P.counters->sched[24 + k], cn.cyc[k]);
     }
 }
 
@@ -662,17 +665,23 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
     int n_parked = 0;
     Counters cn;
 
+    unsigned long long t_begin = 0;
+    if (COUNT) t_begin = __builtin_amdgcn_s_memtime();
     while (w.n_dead < ns) {
+        unsigned long long t0 = 0;
+        if (COUNT) t0 = __builtin_amdgcn_s_memtime();
         const bool starving = w.ray_count == 0 && n_parked == 0; // traversal has nothing to do: shade whatever is queued
         if (w.hit_count >= PT_WAVE || (starving && w.hit_count > 0 && (w.hit_count >= w.miss_count || w.miss_blocked))) {
             shade_pass<COUNT, false>(P, w, lane, cn);
+            if (COUNT) cn.cyc[3] += __builtin_amdgcn_s_memtime() - t0;
         } else if (!w.miss_blocked && (w.miss_count >= PT_WAVE || (starving && w.miss_count > 0))) {
             shade_pass<COUNT, true>(P, w, lane, cn);
+            if (COUNT) cn.cyc[4] += __builtin_amdgcn_s_memtime() - t0;
         } else if (starving && w.hit_count == 0) {
             // every live slot of this wave waits for a chunk that another wave is still rendering
             __builtin_amdgcn_s_sleep(64);
             w.miss_blocked = false;
-            if (COUNT) cn.sched[18] += 1;
+            if (COUNT) { cn.sched[18] += 1; cn.cyc[6] += __builtin_amdgcn_s_memtime() - t0; }
         } else {
             // ======================= TRAVERSAL PHASE ==============================================================
             int pslot = -1;
@@ -697,6 +706,8 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
             }
             bool first = true;
             int n_retire_passes = 0;
+            unsigned long long t1 = 0;
+            if (COUNT) { t1 = __builtin_amdgcn_s_memtime(); cn.cyc[5] += t1 - t0; }
             for (;;) {
                 // idle lanes (pslot < 0) always hold cur == PT_DONE
                 const unsigned long long m_done = __ballot(cur == PT_DONE && pslot >= 0);
@@ -745,19 +756,22 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                         w.ray_count -= take;
                     }
                     const unsigned long long m_busy = __ballot(pslot >= 0);
+                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[2] += t2 - t1; t1 = t2; }
                     if (m_busy == 0ull) break;                                                           // nothing in flight
                     if (++n_retire_passes >= 16) w.miss_blocked = false; // time to poll the waiting tickets again
                     // a full shading batch is ready: go and turn it into rays (a miss queue that only holds unpublished tickets does not count)
                     if (w.hit_count >= PT_WAVE || (!w.miss_blocked && w.miss_count >= PT_WAVE)) break;
                     continue;
                 }
-                // ---- one step for the majority: a BVH node step or a triangle test ----
+                // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
+                // every iteration were measured 3-40 % slower, profiles/r01_sweeps.md) ----
                 if (popc64(m_node) >= popc64(m_leaf)) {
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
                     if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
                         node_step<PT_WAVE>(nodes, stack, o, inv, h.t, cur, sp);
                     }
+                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[0] += t2 - t1; t1 = t2; }
                 } else {
                     if (COUNT) { cn.sched[2] += 1; cn.sched[3] += popc64(m_leaf); }
                     if (cur < PT_DONE) {
@@ -774,6 +788,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                             cur = PT_DONE;
                         }
                     }
+                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[1] += t2 - t1; t1 = t2; }
                 }
             }
             // ---- park unfinished traversals until the next traversal phase ----
@@ -794,6 +809,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
     }
 #undef LF
 #undef LFF
+    if (COUNT) cn.cyc[7] = __builtin_amdgcn_s_memtime() - t_begin;
     flush_counters<COUNT>(P, cn);
 }
 

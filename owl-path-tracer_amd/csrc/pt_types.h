@@ -43,7 +43,7 @@ struct PtTexDesc {
 struct PtCounters {
     unsigned long long samples, rays, nodes, tris, scatters, env_misses, nan_retries;
     // scheduler census of the wavefront kernel (wave-level events and the lanes that took part in them)
-    unsigned long long sched[24];
+    unsigned long long sched[32];
 };
 
 struct PtKernelParams {

@@ -47,6 +47,8 @@ def main():
         cen.update({k: cs[k] for k in ("rays", "nodes", "tris", "scatters", "samples")})
         for a, b in (("node_lanes", "node_steps"), ("tri_lanes", "tri_steps"), ("retired", "retire_passes"), ("hit_items", "hit_passes"), ("miss_items", "miss_passes"), ("winddown_idle", "winddown_iters"), ("idle_sum", "iters"), ("donewait_sum", "iters"), ("active_sum", "iters")):
             cen[a + "/" + b] = round(cen[a] / max(1, cen[b]), 2)
+        cyc = dict(zip(["node", "tri", "retire", "hit_pass", "miss_pass", "park_resume", "sleep", "total"], sc[24:32]))
+        cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
         print(json.dumps(cen))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
                       "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
