@@ -13,7 +13,8 @@
 #include "pt_bvh.h"
 #include "pt_types.h"
 
-extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int variant, int grid, size_t lds_bytes, hipStream_t stream, int count);
+extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
+                                       hipStream_t stream, int count);
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
@@ -57,7 +58,7 @@ struct pt_ctx {
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_chunk_done, d_ring;
+    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_chunk_done, d_ring, d_params;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -272,7 +273,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_chunk_done, &c->d_ring};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_chunk_done, &c->d_ring, &c->d_params};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -535,7 +536,11 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.queue_head = (uint32_t*)c->d_heads.p + l;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
-        HIP_TRY(c, pt_launch_render(&P, c->kernel, grid, lds, stream, c->count));
+        if (c->kernel == 2) { // stream-ordered copy: the previous launch on this stream has finished reading the block
+            if ((rc = ensure(c, c->d_params, sizeof(PtKernelParams)))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_params.p, &P, sizeof(PtKernelParams), hipMemcpyHostToDevice, stream));
+        }
+        HIP_TRY(c, pt_launch_render(&P, (const PtKernelParams*)c->d_params.p, c->kernel, grid, lds, stream, c->count));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;

@@ -593,7 +593,8 @@ PTD int tex_coord(float u, int n)
     return (fl != fl) ? 0 : (fl >= (float)n ? n - 1 : (fl < 0.0f ? 0 : (int)fl));
 }
 // tex2D<float4> on an RGBA8 / nearest / clamp / normalised-coordinates texture (owl.hpp:248-257)
-PTD v3 tex_nearest(const uint32_t* texels, int w, int h, float u, float v)
+template <class TexelPtr>
+PTD v3 tex_nearest(TexelPtr texels, int w, int h, float u, float v)
 {
     int ix = tex_coord(u, w), iy = tex_coord(v, h);
     uint32_t p = texels[(size_t)iy * (size_t)w + (size_t)ix];

@@ -51,6 +51,13 @@ struct Counters {
     uint32_t sched[32] = {}; // wave-uniform scheduler census (wavefront kernel)
 };
 
+// Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
+// address_space(1) pointers: global_load/global_store (vmcnt only) instead of flat_* (vmcnt + lgkmcnt, aperture check).
+#define PT_AS1 __attribute__((address_space(1)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T PT_AS1* gp(T* p) { return (T PT_AS1*)p; }
+__device__ __forceinline__ f32x4 ldg4(const void* base, size_t byte_off) { return *(const f32x4 PT_AS1*)((const char PT_AS1*)base + byte_off); }
 __device__ __forceinline__ float fmin_hw(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float fmax_hw(float a, float b) { return __builtin_fmaxf(a, b); }
 
@@ -73,8 +80,8 @@ __device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, 
 // Moeller-Trumbore, two-sided, kTMin < t; ties in t go to the lower global id (order independent result).
 __device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slot, v3 o, v3 d, Hit& h)
 {
-    const float4* tp = reinterpret_cast<const float4*>(tris + slot);
-    float4 a = tp[0], b = tp[1], c = tp[2];
+    const size_t tb = (size_t)(uint32_t)slot * sizeof(PtTri);
+    const f32x4 a = ldg4(tris, tb), b = ldg4(tris, tb + 16), c = ldg4(tris, tb + 32);
     v3 p0 = V(a.x, a.y, a.z), p1 = V(a.w, b.x, b.y), p2 = V(b.z, b.w, c.x);
     int id = __float_as_int(c.y);
     v3 e1 = p1 - p0, e2 = p2 - p0;
@@ -95,9 +102,9 @@ __device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slo
 template <int STRIDE>
 __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint32_t* stack, v3 o, v3 inv, float tbest, int& cur, int& sp)
 {
-    const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-    float4 a = np[0], b = np[1], c = np[2];
-    int4 ch = reinterpret_cast<const int4*>(np)[3];
+    const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode);
+    const f32x4 a = ldg4(nodes, nb), b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
+    const int2 ch = make_int2(__float_as_int(chf.x), __float_as_int(chf.y));
     float tl, tr;
     bool hl = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tbest, tl);
     bool hr = box_test(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tbest, tr);
@@ -173,7 +180,7 @@ __device__ __forceinline__ int shade_hit(const PtKernelParams& P, const float* m
         if (P.env_use_map && P.env_map.width > 0) {
             float tu, tv;
             uv_on_sphere(ps.dir, tu, tv);
-            radiance = radiance + tex_nearest(P.env_map.texels, P.env_map.width, P.env_map.height, tu, tv);
+            radiance = radiance + tex_nearest(gp(P.env_map.texels), P.env_map.width, P.env_map.height, tu, tv);
             if (COUNT) ++cn.env;
         } else if (P.env_use_auto) {
             radiance = radiance + lerp3(vs(1.0f), V(0.5f, 0.7f, 1.0f), 0.5f * (ps.dir.y + 1.0f));
@@ -183,16 +190,16 @@ __device__ __forceinline__ int shade_hit(const PtKernelParams& P, const float* m
         radiance = radiance * P.env_intensity;
         return SR_END;
     }
-    const float4* tp = reinterpret_cast<const float4*>(P.tris + tslot);
-    float4 a = tp[0], b = tp[1], c = tp[2];
+    const size_t tb = (size_t)(uint32_t)tslot * sizeof(PtTri);
+    const f32x4 a = ldg4(P.tris, tb), b = ldg4(P.tris, tb + 16), c = ldg4(P.tris, tb + 32);
     const int tid = __float_as_int(c.y);
-    const float4* sp4 = reinterpret_cast<const float4*>(P.shade + tid);
-    float4 s0 = sp4[0], s1 = sp4[1], s2 = sp4[2], s3 = sp4[3];
+    const size_t sb = (size_t)(uint32_t)tid * sizeof(PtShade);
+    const f32x4 s0 = ldg4(P.shade, sb), s1 = ldg4(P.shade, sb + 16), s2 = ldg4(P.shade, sb + 32), s3 = ldg4(P.shade, sb + 48);
     int mi = __float_as_int(s2.y);
     Material mat = material_default(); // device.cu:150-154
     int tex_slot = -1;
     if (mi >= 0) {
-        const float* mp = mats + mi * PT_MAT_STRIDE;
+        const float PT_AS1* mp = gp(mats) + mi * PT_MAT_STRIDE;
         mat = material_load(mp);
         tex_slot = __float_as_int(mp[17]);
     }
@@ -208,8 +215,8 @@ __device__ __forceinline__ int shade_hit(const PtKernelParams& P, const float* m
     if (tex_slot >= 0) { // device.cu:75-94
         float tu = fma_(by, s3.z, fma_(bx, s3.x, bw * s2.z));
         float tv = fma_(by, s3.w, fma_(bx, s3.y, bw * s2.w));
-        PtTexDesc td = P.textures[tex_slot];
-        mat.base_color = tex_nearest(td.texels, td.width, td.height, tu, tv);
+        const PtTexDesc PT_AS1* tdp = gp(P.textures) + tex_slot;
+        mat.base_color = tex_nearest(gp(tdp->texels), tdp->width, tdp->height, tu, tv);
     }
     if (COUNT) ++cn.scat;
 
@@ -314,8 +321,9 @@ __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& p
 // agent-scope relaxed atomics (write-through sc1 stores), waits vmcnt(0), then takes a ring position and stores the tagged
 // entry (sc1).  The starting lane polls ITS ring cell with an sc1 load and only then issues the sc1 loads of the state (control
 // dependency).  No fence, no spinning: a slot whose cell is not published yet keeps its ticket and polls again in a later pass.
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(gp(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(gp(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
 __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& k, uint32_t& c, int& px, int& py, uint32_t& rng,
@@ -330,7 +338,7 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
         k = e & 0xffffffu;
         c = ld_agent(P.chunk_done + k);
     }
-    const uint32_t pid = P.pixel_ids[k];
+    const uint32_t pid = gp(P.pixel_ids)[k];
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
     if (c == 0) {
@@ -356,10 +364,11 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k
     if ((int)c + 1 >= P.n_chunks) {
         v3 out = color * (1.0f / (float)P.max_samples);                          // device.cu:247
         size_t ofs = (size_t)px + (size_t)P.width * (size_t)(P.height - 1 - py); // device.cu:251
-        P.out_rgb[3 * ofs] = out.x;
-        P.out_rgb[3 * ofs + 1] = out.y;
-        P.out_rgb[3 * ofs + 2] = out.z;
-        if (P.out_rgba8) P.out_rgba8[ofs] = make_rgba(out);
+        float PT_AS1* orgb = gp(P.out_rgb);
+        orgb[3 * ofs] = out.x;
+        orgb[3 * ofs + 1] = out.y;
+        orgb[3 * ofs + 2] = out.z;
+        if (P.out_rgba8) gp(P.out_rgba8)[ofs] = make_rgba(out);
     } else {
         const uint32_t pid = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
         st_agent(P.rng_state + pid, rng);
@@ -369,7 +378,7 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k
         st_agent(a + 2, __float_as_uint(color.z));
         st_agent(P.chunk_done + k, c + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state has left this CU before the ring entry does
-        const uint32_t pos = atomicAdd(P.ring_tail, 1u);  // starts at n_pixels
+        const uint32_t pos = take_agent(P.ring_tail); // starts at n_pixels
         st_agent(P.ring + pos % P.n_pixels, k | ((pos / P.n_pixels) << 24));
     }
 }
@@ -495,7 +504,7 @@ namespace {
 
 struct WaveCtx {
     uint32_t* lray;   // LDS
-    uint32_t* gstate; // global, this wave's region
+    uint32_t PT_AS1* gstate; // global, this wave's region
     uint8_t *rayq, *hitq, *missq;
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
@@ -510,7 +519,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 {
     const int ns = w.ns;
     uint32_t* lray = w.lray;
-    uint32_t* gstate = w.gstate;
+    uint32_t PT_AS1* gstate = w.gstate;
 #define LF(f, s) lray[(f) * ns + (s)]
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 #define GF(f, s) gstate[(f) * ns + (s)]
@@ -569,7 +578,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = atomicAdd(P.queue_head, 1u); // hipcc aggregates this into one atomic per wave
+                if (ticket == PT_FRESH) ticket = take_agent(P.queue_head); // hipcc aggregates this into one atomic per wave
                 if (ticket >= P.n_tickets) {
                     died = true;
                 } else if (start_chunk(P, ticket, qk, chunk, px, py, ps.rng, color)) {
@@ -632,15 +641,19 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 } // namespace
 
 template <bool COUNT>
-__global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams P)
+__global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
 {
+    // The parameter block lives in HBM and is read with scalar loads where it is used.  Passed by value it arrives as
+    // s_load_dwordx16 tuples that stay live for the whole kernel; the register allocator then spilled them to VGPR lanes
+    // and re-read all 16 with v_readlane in EVERY node step just to get the `nodes` pointer.
+    const PtKernelParams& P = *Pp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const int ns = P.ns;
     uint32_t* stack = lds + lane;                        // stack[level * 64]
     uint32_t* lray = lds + P.stack_entries * PT_WAVE;    // lray[field * ns + slot]
-    uint32_t* gstate = P.slot_state + (size_t)blockIdx.x * ((size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE);
-    uint32_t* park = gstate + (size_t)G_NFIELDS * ns + lane; // park[field * 64]
+    uint32_t PT_AS1* gstate = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE);
+    uint32_t PT_AS1* park = gstate + (size_t)G_NFIELDS * ns + lane; // park[field * 64]
     WaveCtx w;
     w.lray = lray;
     w.gstate = gstate;
@@ -885,14 +898,16 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
 
 // ---- launchers (called from pt_api.cpp) --------------------------------------------------------------------
 
-extern "C" hipError_t pt_launch_render(const PtKernelParams* p, int variant, int grid, size_t lds_bytes, hipStream_t stream, int count)
+// d_params: device copy of *p (wavefront kernel reads its parameters from HBM; the caller keeps it stream-ordered)
+extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
+                                       hipStream_t stream, int count)
 {
     if (variant == 1) {
         if (count) hipLaunchKernelGGL(pt_render_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds_bytes, stream, *p);
         else hipLaunchKernelGGL(pt_render_kernel<false>, dim3(grid), dim3(PT_BLOCK), lds_bytes, stream, *p);
     } else {
-        if (count) hipLaunchKernelGGL(pt_render_wave_kernel<true>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, *p);
-        else hipLaunchKernelGGL(pt_render_wave_kernel<false>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, *p);
+        if (count) hipLaunchKernelGGL(pt_render_wave_kernel<true>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+        else hipLaunchKernelGGL(pt_render_wave_kernel<false>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
     }
     return hipGetLastError();
 }
