@@ -1,0 +1,237 @@
+// main.cpp -- host entry point with the reference's file-level behaviour (path_tracer/Main.cpp:13-31,
+// path_tracer/src/application.cpp:143-181,297-371, application.hpp:89-108): read CWD/assets/settings.json, <scene>.json,
+// <scene>.obj.scene (+ environment.hdr, textures), then run the material sweep ("test_loop") and write one PNG per step as
+// <scene>_<test.name>_<attribute_name>(<value>).png in the CWD.  The render itself goes through the C-ABI (mi355pt.h).
+//
+// Optional flags (defaults reproduce the reference, which has no CLI): --assets DIR, --out DIR, --settings FILE, --device N
+// (-1: load + build only, no render), --dump-scene FILE (binary dump of the ingested scene for the loader tests).
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "image_io.h"
+#include "scene_loader.h"
+
+namespace {
+
+bool file_exists(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0;
+}
+
+void dump_scene(const std::string& path, const host::Scene& s)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    auto w32 = [&](int32_t v) { std::fwrite(&v, 4, 1, f); };
+    auto wstr = [&](const std::string& t) { w32((int32_t)t.size()); std::fwrite(t.data(), 1, t.size(), f); };
+    std::fwrite("PTSC", 1, 4, f);
+    std::fwrite(&s.camera, sizeof(float), 10, f);
+    w32((int32_t)s.materials.size());
+    for (auto const& m : s.materials) { wstr(m.name); std::fwrite(m.data.data(), 4, host::kMatFloats, f); wstr(m.texture_file); }
+    w32((int32_t)s.meshes.size());
+    for (auto const& m : s.meshes) {
+        wstr(m.name);
+        w32((int32_t)(m.vertices.size() / 3)); w32((int32_t)(m.normals.size() / 3)); w32((int32_t)(m.texcoords.size() / 2)); w32((int32_t)(m.indices.size() / 3));
+        std::fwrite(m.vertices.data(), 4, m.vertices.size(), f);
+        std::fwrite(m.normals.data(), 4, m.normals.size(), f);
+        std::fwrite(m.texcoords.data(), 4, m.texcoords.size(), f);
+        std::fwrite(m.indices.data(), 4, m.indices.size(), f);
+    }
+    w32((int32_t)s.entities.size());
+    for (auto const& e : s.entities) { w32(e.mesh); w32(e.material); }
+    std::fclose(f);
+}
+
+std::string fmt1(float v)
+{
+    char b[64];
+    std::snprintf(b, sizeof(b), "%.1f", v); // fmt "{:.1f}" (application.hpp:101-105)
+    return b;
+}
+
+struct App {
+    host::Settings settings;
+    host::Scene scene;
+    std::vector<float> materials; // n * 17
+    pt_ctx* ctx = nullptr;
+    pt_camera cam{};
+    std::string out_dir;
+};
+
+void check(App& a, int rc, const char* what)
+{
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + pt_last_error(a.ctx));
+}
+
+// render_frame, application.cpp:363-371
+void render_frame(App& a, const std::string& values)
+{
+    std::fprintf(stderr, "TRACING\n");
+    const int W = a.settings.buffer_size[0], H = a.settings.buffer_size[1];
+    std::vector<float> rgb((size_t)W * H * 3);
+    std::vector<uint32_t> rgba((size_t)W * H);
+    check(a, pt_render(a.ctx, &a.cam, W, H, a.settings.max_samples, a.settings.max_path_depth, rgb.data(), rgba.data()), "pt_render");
+    pt_stats st;
+    pt_get_stats(a.ctx, &st);
+    std::string name = a.settings.scene + "_" + a.settings.test.name + "_" + a.settings.test.attribute_name + "(" + values + ").png";
+    std::string path = a.out_dir + "/" + name;
+    imgio::write_png_rgba8(path, W, H, rgba.data());
+    std::printf("Image written to %s\n", path.c_str());
+    std::fprintf(stderr, "  %.1f ms kernel, %.1f Msamples/s\n", st.kernel_ms, (double)W * H * a.settings.max_samples / (st.kernel_ms * 1e3));
+}
+
+float* find_material(App& a)
+{ // get_material, application.cpp:307-317 (the reference dereferences end() when the name is unknown; we report it)
+    for (size_t i = 0; i < a.scene.materials.size(); ++i)
+        if (a.scene.materials[i].name == a.settings.test.material_name) return &a.materials[i * host::kMatFloats];
+    throw std::runtime_error("test.material_name '" + a.settings.test.material_name + "' is not a material of the scene");
+}
+
+// test_loop<T>, application.hpp:89-108
+void test_loop(App& a)
+{
+    const host::TestData& t = a.settings.test;
+    const int vstep = (int)(t.step_size * 100);
+    if (vstep <= 0) throw std::runtime_error("test.step_size * 100 < 1: the reference would loop forever (application.hpp:94-95)");
+    const bool vec = !t.vec_values.empty(); // Main.cpp:25-28
+    if (vec ? t.vec_values.size() < 2 : t.flt_values.size() < 2) throw std::runtime_error("test.values needs two entries");
+    float* mat = find_material(a);
+    const int attr = host::attribute_index(t.attribute_name);
+    for (int i = 0; i <= 100; i += vstep) {
+        const float c = i / 100.0f;
+        std::string values;
+        if (vec) { // modify_sbt(vec3): base_color (application.cpp:320-326)
+            for (int k = 0; k < 3; ++k) {
+                float v = t.vec_values[0][k] + (t.vec_values[1][k] - t.vec_values[0][k]) * c;
+                mat[k] = v;
+                values += (k ? "," : "") + fmt1(v);
+            }
+        } else { // modify_sbt(float): one named attribute; unknown names change nothing (application.cpp:329-360)
+            float v = t.flt_values[0] + (t.flt_values[1] - t.flt_values[0]) * c;
+            if (attr >= 0) mat[attr] = v;
+            values = fmt1(v);
+        }
+        check(a, pt_set_materials(a.ctx, a.materials.data(), (int32_t)a.scene.materials.size()), "pt_set_materials"); // reset_field
+        render_frame(a, values);
+    }
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    try {
+        App a;
+        char cwd[4096];
+        if (!getcwd(cwd, sizeof(cwd))) throw std::runtime_error("getcwd failed");
+        std::string assets = std::string(cwd) + "/assets"; // Main.cpp:17
+        std::string settings_path, dump;
+        a.out_dir = cwd;
+        int device = 0;
+        for (int i = 1; i < argc; ++i) {
+            std::string k = argv[i];
+            auto next = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value for " + k); return std::string(argv[++i]); };
+            if (k == "--assets") assets = next();
+            else if (k == "--out") a.out_dir = next();
+            else if (k == "--settings") settings_path = next();
+            else if (k == "--device") device = std::atoi(next().c_str());
+            else if (k == "--dump-scene") dump = next();
+            else if (k == "--convert-png" || k == "--convert-hdr") { // codec self-test hooks: decode with our reader, re-encode with our writer
+                std::string in = next(), out = next();
+                imgio::Image img = k == "--convert-png" ? imgio::load_png_rgba8(in) : imgio::load_hdr_as_ldr_rgba8(in);
+                imgio::write_png_rgba8(out, img.width, img.height, img.rgba.data());
+                return 0;
+            }
+            else throw std::runtime_error("unknown option " + k);
+        }
+        if (settings_path.empty()) settings_path = assets + "/settings.json"; // application.cpp:145
+
+        std::fprintf(stderr, "Parsing settings\n");
+        a.settings = host::parse_settings(settings_path);
+        std::fprintf(stderr, "Parsing camera\nParsing materials\n");
+        a.scene = host::load_scene(assets, a.settings.scene);
+        for (auto const& m : a.scene.materials) std::fprintf(stderr, " - %s\n", m.name.c_str());
+        if (!dump.empty()) dump_scene(dump, a.scene);
+
+        // environment map (application.cpp:160; image_buffer.cpp:36-58)
+        imgio::Image env_img;
+        const std::string env_path = assets + "/environment.hdr";
+        if (file_exists(env_path)) {
+            env_img = imgio::load_hdr_as_ldr_rgba8(env_path);
+            imgio::flip_vertical(env_img);
+        } else {
+            std::fprintf(stderr, "Image file %s does not exist. Continue with empty.\n", env_path.c_str());
+        }
+
+        // entities -> pt_mesh (application.cpp:186-247)
+        std::vector<pt_mesh> meshes;
+        std::vector<imgio::Image> tex_images;
+        std::vector<int> tex_of_material(a.scene.materials.size(), -1);
+        for (auto const& e : a.scene.entities) {
+            const host::Mesh& m = a.scene.meshes[e.mesh];
+            pt_mesh pm{};
+            pm.vertices = m.vertices.data(); pm.n_vertices = (int32_t)(m.vertices.size() / 3);
+            pm.normals = m.normals.empty() ? nullptr : m.normals.data(); pm.n_normals = (int32_t)(m.normals.size() / 3);
+            pm.texcoords = m.texcoords.empty() ? nullptr : m.texcoords.data(); pm.n_texcoords = (int32_t)(m.texcoords.size() / 2);
+            pm.indices = m.indices.data(); pm.n_triangles = (int32_t)(m.indices.size() / 3);
+            pm.material_index = e.material;
+            pm.texture_index = -1;
+            const std::string& tf = a.scene.materials[e.material].texture_file;
+            if (!tf.empty()) {
+                if (tex_of_material[e.material] < 0) {
+                    const std::string tp = assets + "/" + tf;
+                    if (file_exists(tp)) {
+                        imgio::Image img = imgio::load_png_rgba8(tp);
+                        imgio::flip_vertical(img); // application.cpp:229-234
+                        tex_of_material[e.material] = (int)tex_images.size();
+                        tex_images.push_back(std::move(img));
+                    } else {
+                        // The reference prints this warning and RETURNS from bind_sbt_data, leaving the pipeline unbuilt
+                        // (application.cpp:219-223, a bug).  Documented divergence: render the entity untextured.
+                        std::fprintf(stderr, "Image file %s does not exist. Continue with empty.\n", tp.c_str());
+                    }
+                }
+                pm.texture_index = tex_of_material[e.material];
+            }
+            meshes.push_back(pm);
+        }
+        std::vector<pt_texture> textures;
+        for (auto const& img : tex_images) textures.push_back({img.width, img.height, img.rgba.data()});
+        for (auto const& m : a.scene.materials) a.materials.insert(a.materials.end(), m.data.begin(), m.data.end());
+
+        pt_env env{};
+        env.use_map = a.settings.environment_use;
+        env.use_auto = a.settings.environment_auto;
+        for (int i = 0; i < 3; ++i) env.color[i] = a.settings.environment_color[i];
+        env.intensity = a.settings.environment_intensity;
+        env.map = {env_img.width, env_img.height, env_img.rgba.empty() ? nullptr : env_img.rgba.data()};
+
+        pt_config cfg{device, 0};
+        a.ctx = pt_create(&cfg);
+        if (!a.ctx) throw std::runtime_error(std::string("pt_create: ") + pt_last_error(nullptr));
+        if (meshes.empty()) throw std::runtime_error("no geometries"); // application.cpp:133
+        check(a, pt_upload_scene(a.ctx, meshes.data(), (int32_t)meshes.size(), a.materials.data(), (int32_t)a.scene.materials.size(),
+                                 textures.data(), (int32_t)textures.size(), nullptr, &env), "pt_upload_scene");
+        pt_to_camera_data(a.scene.camera.look_from, a.scene.camera.look_at, a.scene.camera.look_up, a.scene.camera.vertical_fov,
+                          a.settings.buffer_size[0], a.settings.buffer_size[1], &a.cam); // parse_camera -> to_camera_data
+        pt_stats st;
+        pt_get_stats(a.ctx, &st);
+        std::fprintf(stderr, "scene '%s': %llu triangles in %zu entities, BVH %llu nodes depth %llu (%.1f ms)\n", a.settings.scene.c_str(),
+                     (unsigned long long)st.n_triangles, meshes.size(), (unsigned long long)st.bvh_nodes, (unsigned long long)st.bvh_depth, st.bvh_build_ms);
+        if (device >= 0) test_loop(a);
+        else std::fprintf(stderr, "--device -1: scene loaded and BVH built, no render\n");
+        pt_destroy(a.ctx); // Main.cpp:30
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}
