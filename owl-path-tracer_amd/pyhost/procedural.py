@@ -40,13 +40,16 @@ def quad(p0, p1, p2, p3, normal, uv=False):
     return _mesh(v, n, idx, tc)
 
 
-def uv_sphere(center, radius, nu=64, nv=32, flip=False):
-    """Latitude/longitude sphere with duplicated pole rings (all faces are proper triangles)."""
+def uv_sphere(center, radius, nu=64, nv=32, flip=False, scale=(1.0, 1.0, 1.0)):
+    """Latitude/longitude sphere (or axis-aligned ellipsoid via `scale`) with duplicated pole rings (all faces proper triangles)."""
     u = (np.arange(nu) / nu) * 2 * np.pi
     v = (np.arange(nv + 1) / nv) * np.pi
     uu, vv = np.meshgrid(u, v, indexing="ij")
     n = np.stack([np.sin(vv) * np.cos(uu), np.cos(vv), np.sin(vv) * np.sin(uu)], -1)
-    p = np.asarray(center, np.float64) + radius * n
+    sc = np.asarray(scale, np.float64)
+    p = np.asarray(center, np.float64) + radius * n * sc
+    n = n / sc  # ellipsoid normal ~ (x/sx^2, y/sy^2, z/sz^2)
+    n = n / np.linalg.norm(n, axis=-1, keepdims=True)
     idx = _grid_indices(nu, nv + 1, wrap_u=True, wrap_v=False)
     # drop degenerate triangles at the poles
     P = p.reshape(-1, 3)
@@ -118,6 +121,97 @@ def mitsuba_standin(detail=96):
 def furnace_sphere(detail=48):
     """Unit-test scene: the object 'sphere' of assets/sphere.json (geometry blob missing upstream)."""
     return [("sphere", uv_sphere((0, 1, 0), 1.0, nu=2 * detail, nv=detail))]
+
+
+def torus(center, R, r, nu=128, nv=48, axis=0):
+    """Torus of major radius R / minor radius r around coordinate axis `axis` (wheel stand-in)."""
+    u = (np.arange(nu) / nu) * 2 * np.pi
+    v = (np.arange(nv) / nv) * 2 * np.pi
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    a = (R + r * np.cos(vv)) * np.cos(uu)
+    b = (R + r * np.cos(vv)) * np.sin(uu)
+    c = r * np.sin(vv)
+    na, nb, nc = np.cos(vv) * np.cos(uu), np.cos(vv) * np.sin(uu), np.sin(vv)
+    order = {0: (2, 0, 1), 1: (0, 2, 1), 2: (0, 1, 2)}[axis]  # which of (a, b, c) goes to x, y, z
+    comp, ncomp = (a, b, c), (na, nb, nc)
+    P = np.stack([comp[order[0]], comp[order[1]], comp[order[2]]], -1) + np.asarray(center, np.float64)
+    N = np.stack([ncomp[order[0]], ncomp[order[1]], ncomp[order[2]]], -1)
+    return _mesh(P.reshape(-1, 3), N.reshape(-1, 3), _grid_indices(nu, nv))
+
+
+def car_standin(detail=1.0):
+    """C5 stand-in carrying all 12 material names of assets/car.json (car.obj.scene is a missing blob): body ellipsoid with
+    clearcoat paint, glass canopy (rough-glass lobe, inside/outside transitions), anisotropic carbon, metals, tyres, interior
+    parts seen through the glass, textured ground (uv), emissive light.  1.72 M triangles at detail=1."""
+    d = lambda n: max(8, int(round(n * detail)))
+    parts = [
+        ("BodyMat", uv_sphere((0, 0.62, 0), 1.0, d(1200), d(600), scale=(0.95, 0.42, 2.1))),
+        ("WindowGlassMat", uv_sphere((0, 1.02, -0.15), 1.0, d(256), d(128), scale=(0.7, 0.4, 1.05))),
+        ("Interior_Red", uv_sphere((-0.3, 0.95, -0.1), 0.22, d(96), d(48))),
+        ("Interior_Black", uv_sphere((0.3, 0.95, -0.1), 0.22, d(96), d(48))),
+        ("BodyMat_BK", uv_sphere((0, 0.45, 2.05), 0.35, d(128), d(64), scale=(2.2, 0.5, 0.5))),
+        ("BodyGlossBlackMat", uv_sphere((0, 0.45, -2.05), 0.35, d(128), d(64), scale=(2.2, 0.5, 0.5))),
+        ("CarbonBlack", uv_sphere((0, 1.25, -1.75), 0.3, d(128), d(64), scale=(2.6, 0.15, 0.6))),
+        ("Default", uv_sphere((1.6, 0.3, 1.2), 0.3, d(96), d(48))),
+    ]
+    tyres, hubs = [], []
+    for sx in (-1, 1):
+        for sz in (-1.25, 1.25):
+            tyres.append(torus((sx * 0.88, 0.36, sz), 0.24, 0.12, d(256), d(64), axis=0))
+            hubs.append(uv_sphere((sx * 0.9, 0.36, sz), 0.16, d(64), d(32), scale=(0.5, 1, 1)))
+    parts.append(("TireMat", merge_meshes(tyres)))
+    parts.append(("EngineSilver2", merge_meshes(hubs)))
+    parts.append(("Ground", quad((-10, 0, -10), (-10, 0, 10), (10, 0, 10), (10, 0, -10), (0, 1, 0), uv=True)))
+    parts.append(("Light", quad((-1.5, 5.0, -1.5), (1.5, 5.0, -1.5), (1.5, 5.0, 1.5), (-1.5, 5.0, 1.5), (0, -1, 0))))
+    return parts
+
+
+def merge_meshes(ms):
+    v, n, tc, idx, off = [], [], [], [], 0
+    for m in ms:
+        v.append(m["vertices"]); n.append(m["normals"]); tc.append(m["texcoords"])
+        idx.append(m["indices"] + off)
+        off += m["vertices"].shape[0]
+    return dict(vertices=np.concatenate(v), normals=np.concatenate(n), texcoords=np.concatenate(tc), indices=np.concatenate(idx).astype(np.int32))
+
+
+def synthetic_sky_rgbe(width=2048, height=1024):
+    """Closed-form lat-long sky + sun as Radiance RGBE bytes (H, W, 4) (stand-in for the missing assets/environment.hdr)."""
+    v, u = np.mgrid[0:height, 0:width]
+    el = (0.5 - (v + 0.5) / height) * np.pi          # +pi/2 at the top row
+    az = ((u + 0.5) / width - 0.5) * 2 * np.pi
+    d = np.stack([np.cos(el) * np.sin(az), np.sin(el), np.cos(el) * np.cos(az)], -1)
+    sun = np.array([0.4, 0.7, 0.59]); sun /= np.linalg.norm(sun)
+    mu = (d * sun).sum(-1)
+    t = np.clip(d[..., 1], 0, 1)
+    sky = (1 - t)[..., None] * np.array([0.9, 0.9, 0.95]) + t[..., None] * np.array([0.25, 0.45, 0.95])
+    ground = np.array([0.18, 0.16, 0.14])
+    rgb = np.where(d[..., 1:2] >= 0, sky, ground) + (np.exp((mu - 1) * 2000.0) * 60.0 + np.exp((mu - 1) * 40.0) * 0.6)[..., None]
+    m = rgb.max(-1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0)
+    scale = np.where(m > 1e-32, np.ldexp(1.0, (8 - e).astype(np.int32)), 0.0)
+    out = np.zeros((height, width, 4), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    return out
+
+
+def write_hdr(path, rgbe):
+    """Flat (non-RLE) Radiance file."""
+    h, w = rgbe.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        f.write(np.ascontiguousarray(rgbe).tobytes())
+
+
+def rgbe_to_ldr_rgba8(rgbe, flip=True):
+    """stb_image's HDR->LDR conversion (extern/stb/stb_image.h:1864-1890: pow(x, 1/2.2)*255+0.5, clamp) followed by the
+    reference's vertical flip (image_buffer.cpp:50-55): the (H, W) uint32 environment texture the render path samples."""
+    f1 = np.where(rgbe[..., 3:4] == 0, 0.0, np.ldexp(1.0, rgbe[..., 3:4].astype(np.int32) - 136)).astype(np.float32)
+    lin = rgbe[..., :3].astype(np.float32) * f1
+    z = np.clip(np.power(lin, np.float32(1.0 / 2.2)) * np.float32(255) + np.float32(0.5), 0, 255).astype(np.uint32)
+    img = (z[..., 0] | (z[..., 1] << 8) | (z[..., 2] << 16) | np.uint32(0xFF000000)).astype(np.uint32)
+    return np.ascontiguousarray(img[::-1]) if flip else img
 
 
 def write_obj(path, meshes):

@@ -390,3 +390,43 @@ def test_c4_dragon_standin_full_size(gpu, orc, scene_io, procedural):
     assert not part[~own].any()
     assert_bitwise(part[own], a[own], "shard 3/8 == full image on its tiles")
     print("C4 kernel_ms=%.1f Msamples/s=%.1f" % (st["kernel_ms"], W * H * 1024 / st["kernel_ms"] / 1e3))
+
+
+def test_c3_mitsuba_standin_full_size(gpu, orc, scene_io, procedural):
+    """BASELINE C3 on the documented stand-in: mitsuba.json, 1024x1024, 512 spp, depth 16, environment_auto (no emitter)."""
+    _, mats = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "mitsuba.json"))
+    ents = scene_io.build_entities(procedural.mitsuba_standin(), mats)
+    env = dict(use_auto=True, intensity=1.0)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
+    W = H = 1024
+    cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    a, _ = gpu.render(cam, W, H, 512, 16)
+    st = gpu.stats()
+    S = orc.Scene(scene_io.flatten_scene(ents, mats))
+    _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 512, 16, 800, 5)
+    assert a.mean() > 0.05
+    print("C3 kernel_ms=%.1f Msamples/s=%.1f" % (st["kernel_ms"], W * H * 512 / st["kernel_ms"] / 1e3))
+
+
+def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
+    """BASELINE C5 on the documented stand-ins: car.json (12 materials: glass, clearcoat, anisotropic metal, textured ground,
+    emitter), synthetic 2048x1024 HDR sky through stb's 8-bit tone map, 1920x1080, 4096 spp, depth 16, environment_use."""
+    _, mats = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "car.json"))
+    ents = scene_io.build_entities(procedural.car_standin(), mats)
+    names = [n for n, _, _ in mats]
+    gi = names.index("Ground")
+    tex = scene_io.checker_texture(256, 256, 16)
+    envmap = procedural.rgbe_to_ldr_rgba8(procedural.synthetic_sky_rgbe(2048, 1024))
+    env = dict(use_map=True, intensity=1.0, env_map=envmap)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
+    assert gpu.stats()["n_triangles"] > 1_500_000
+    W, H = 1920, 1080
+    cam = B.to_camera_data([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, W, H)
+    gpu.set_option("count", 1)
+    a, _ = gpu.render(cam, W, H, 4096, 16)
+    st = gpu.stats()
+    gpu.set_option("count", 0)
+    assert np.isfinite(a).all() and st["env_misses"] > 0 and st["samples"] == W * H * 4096
+    S = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
+    _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 4096, 16, 160, 6)
+    print("C5 (counted) kernel_ms=%.1f Msamples/s=%.1f rays/sample=%.2f" % (st["kernel_ms"], W * H * 4096 / st["kernel_ms"] / 1e3, st["rays"] / st["samples"]))
