@@ -467,10 +467,11 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         n_launch = 1;
         if (n_chunks > 255 || c->n_pixels >= (1u << 24)) return fail(c, PT_E_LIMIT, "ring tags need n_chunks <= 255 and < 2^24 pixels (raise chunk_spp)");
         if ((rc = ensure(c, c->d_chunk_done, (size_t)c->n_pixels * 4))) return rc;
-        if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 + 4))) return rc; // cells + tail counter
+        if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 + 8))) return rc; // cells + tail counter + watchdog flag
         HIP_TRY(c, hipMemsetAsync(c->d_chunk_done.p, 0, (size_t)c->n_pixels * 4, stream));
         HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4, stream));
         HIP_TRY(c, hipMemcpyAsync((uint32_t*)c->d_ring.p + c->n_pixels, &c->n_pixels, 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(c, hipMemsetAsync((uint32_t*)c->d_ring.p + c->n_pixels + 1, 0, 4, stream));
     }
     if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 4))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 4, stream));
@@ -502,6 +503,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.chunk_done = (uint32_t*)c->d_chunk_done.p;
     P.ring = (uint32_t*)c->d_ring.p;
     P.ring_tail = c->d_ring.p ? (uint32_t*)c->d_ring.p + c->n_pixels : nullptr;
+    P.error_flag = c->d_ring.p ? (uint32_t*)c->d_ring.p + c->n_pixels + 1 : nullptr;
     P.chunk_spp = chunk;
     P.n_chunks = n_chunks;
     P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
@@ -510,7 +512,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 160; // measured best on C4 (128..255 swept, profiles/r01_sweeps.md)
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 128; // 96..255 swept on C4 (profiles/r01_summary.md)
     HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
         // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
@@ -575,9 +577,12 @@ int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max
     if (out_rgba8 && (rc = ensure(c, c->d_out8, npx * 4))) return rc;
     rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, nullptr);
     if (rc) return rc;
+    uint32_t wd = 0;
+    if (c->kernel == 2 && c->d_ring.p) HIP_TRY(c, hipMemcpyAsync(&wd, (uint32_t*)c->d_ring.p + c->n_pixels + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
     if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (wd) return fail(c, PT_E_HIP, "render kernel watchdog fired (scheduler made no progress); the image is incomplete");
     return PT_OK;
 }
 

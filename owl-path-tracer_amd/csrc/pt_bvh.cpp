@@ -129,8 +129,8 @@ struct Builder {
         int32_t rc = build(mid, hi, depth + 1, balanced);
         PtNode& nd = out->nodes[idx];
         for (int a = 0; a < 3; ++a) {
-            nd.lmin[a] = l.mn[a] - pad; nd.lmax[a] = l.mx[a] + pad;
-            nd.rmin[a] = r.mn[a] - pad; nd.rmax[a] = r.mx[a] + pad;
+            nd.lo[a][0] = l.mn[a] - pad; nd.hi[a][0] = l.mx[a] + pad;
+            nd.lo[a][1] = r.mn[a] - pad; nd.hi[a][1] = r.mx[a] + pad;
         }
         nd.left = lc;
         nd.right = rc;
@@ -229,8 +229,10 @@ bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float d
         if (cur >= 0) {
             const PtNode& nd = bvh.nodes[cur];
             float tl, tr;
-            bool hl = hbox(nd.lmin, nd.lmax, o, inv, tmin, bt, &tl);
-            bool hr = hbox(nd.rmin, nd.rmax, o, inv, tmin, bt, &tr);
+            const float lmin[3] = {nd.lo[0][0], nd.lo[1][0], nd.lo[2][0]}, lmax[3] = {nd.hi[0][0], nd.hi[1][0], nd.hi[2][0]};
+            const float rmin[3] = {nd.lo[0][1], nd.lo[1][1], nd.lo[2][1]}, rmax[3] = {nd.hi[0][1], nd.hi[1][1], nd.hi[2][1]};
+            bool hl = hbox(lmin, lmax, o, inv, tmin, bt, &tl);
+            bool hr = hbox(rmin, rmax, o, inv, tmin, bt, &tr);
             if (hl && hr) {
                 bool swap = tr < tl;
                 stack[sp++] = swap ? nd.left : nd.right;

@@ -33,6 +33,15 @@ using namespace ptd;
 #ifndef PT_NS_DEFAULT
 #define PT_NS_DEFAULT 192  // path slots per wave: >= 64 + 2*63 + 1 so that an empty ray queue implies a full hit or miss batch
 #endif
+#ifndef PT_WATCHDOG_ROUNDS
+#define PT_WATCHDOG_ROUNDS 20000000 // wave-loop rounds (shading passes + traversal phases) before a wave gives up; a C5 frame needs ~2e5 per wave
+#endif
+#ifndef PT_RAY_LOW
+#define PT_RAY_LOW 32      // ray-queue level below which a partial shading batch is worth it
+#endif
+#ifndef PT_MIN_BATCH
+#define PT_MIN_BATCH 32    // smallest shading batch taken early
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -49,6 +58,7 @@ struct Counters {
     uint32_t rays = 0, nodes = 0, tris = 0, scat = 0, env = 0, samples = 0, retry = 0;
     unsigned long long cyc[8] = {}; // COUNT build: shader-clock cycles per phase {node steps, tri steps, retire, hit pass, miss pass, park/resume, sleep, total}
     uint32_t sched[32] = {}; // wave-uniform scheduler census (wavefront kernel)
+    uint32_t depth[4] = {};  // per lane: pushes, pushes at stack depth >= 8 / 12 / 16
 };
 
 // Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
@@ -99,29 +109,59 @@ __device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slo
 }
 
 // One BVH-node step for a lane: test both children, descend into the nearer hit child, push the other.
-template <int STRIDE>
-__device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint32_t* stack, v3 o, v3 inv, float tbest, int& cur, int& sp)
+// Stack entry i lives in LDS (stack[i * STRIDE]) for i < LDS_ENTRIES, else in the lane's HBM overflow column
+// (ovf[(i - LDS_ENTRIES) * STRIDE]): on C4 0.006 % of the pushes go deeper than 12 (profiles/r01_sweeps.md), so a 12-entry LDS
+// stack halves the LDS a wave needs for BVHs of any depth.  LDS_ENTRIES = 0x7fffffff: everything in LDS.
+template <int STRIDE, int LDS_ENTRIES>
+__device__ __forceinline__ void stack_push(uint32_t* stack, uint32_t PT_AS1* ovf, int sp, uint32_t v)
+{
+    if (LDS_ENTRIES == 0x7fffffff || sp < LDS_ENTRIES) stack[sp * STRIDE] = v;
+    else ovf[(sp - LDS_ENTRIES) * STRIDE] = v;
+}
+template <int STRIDE, int LDS_ENTRIES>
+__device__ __forceinline__ uint32_t stack_pop(uint32_t* stack, uint32_t PT_AS1* ovf, int sp)
+{
+    if (LDS_ENTRIES == 0x7fffffff || sp < LDS_ENTRIES) return stack[sp * STRIDE];
+    return ovf[(sp - LDS_ENTRIES) * STRIDE];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int STRIDE, int LDS_ENTRIES>
+__device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest, int& cur,
+                                          int& sp, uint32_t* depth_census = nullptr)
 {
     const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode);
     const f32x4 a = ldg4(nodes, nb), b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
-    const int2 ch = make_int2(__float_as_int(chf.x), __float_as_int(chf.y));
-    float tl, tr;
-    bool hl = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tbest, tl);
-    bool hr = box_test(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tbest, tr);
+    const int chl = __float_as_int(chf.x), chr = __float_as_int(chf.y);
+    // slab test of both children at once, {left, right} in the two halves of packed-f32 registers.  Same IEEE operations as
+    // box_test: (bound - o) * inv, min/max ignoring NaN, far side scaled by 1.0000004.
+    const f32x2 lox = {a.x, a.y}, loy = {a.z, a.w}, loz = {b.x, b.y}, hix = {b.z, b.w}, hiy = {c.x, c.y}, hiz = {c.z, c.w};
+    const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const f32x2 t0x = (lox - ox) * ix, t1x = (hix - ox) * ix;
+    const f32x2 t0y = (loy - oy) * iy, t1y = (hiy - oy) * iy;
+    const f32x2 t0z = (loz - oz) * iz, t1z = (hiz - oz) * iz;
+    const float tl = fmax_hw(fmax_hw(fmin_hw(t0x.x, t1x.x), fmin_hw(t0y.x, t1y.x)), fmax_hw(fmin_hw(t0z.x, t1z.x), kTMin));
+    const float tr = fmax_hw(fmax_hw(fmin_hw(t0x.y, t1x.y), fmin_hw(t0y.y, t1y.y)), fmax_hw(fmin_hw(t0z.y, t1z.y), kTMin));
+    f32x2 tf = {fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmin_hw(fmax_hw(t0z.x, t1z.x), tbest)),
+                fmin_hw(fmin_hw(fmax_hw(t0x.y, t1x.y), fmax_hw(t0y.y, t1y.y)), fmin_hw(fmax_hw(t0z.y, t1z.y), tbest))};
+    const f32x2 pad = {1.0000004f, 1.0000004f};
+    tf = tf * pad;
+    const bool hl = tl <= tf.x, hr = tr <= tf.y;
+    // near child first; the far one is pushed only when both are hit
+    const bool right_first = hr && (!hl || tr < tl);
+    const int nearc = right_first ? chr : chl;
+    const int farc = right_first ? chl : chr;
     if (hl && hr) {
-        bool swap = tr < tl;
-        int nearc = swap ? ch.y : ch.x;
-        int farc = swap ? ch.x : ch.y;
-        stack[sp * STRIDE] = (uint32_t)farc;
+        stack_push<STRIDE, LDS_ENTRIES>(stack, ovf, sp, (uint32_t)farc);
+        if (depth_census) { depth_census[0] += 1; depth_census[1] += sp >= 8; depth_census[2] += sp >= 12; depth_census[3] += sp >= 16; }
         ++sp;
+    }
+    if (hl || hr) {
         cur = nearc;
-    } else if (hl) {
-        cur = ch.x;
-    } else if (hr) {
-        cur = ch.y;
     } else if (sp > 0) {
         --sp;
-        cur = (int)stack[sp * STRIDE];
+        cur = (int)stack_pop<STRIDE, LDS_ENTRIES>(stack, ovf, sp);
     } else {
         cur = PT_DONE;
     }
@@ -139,7 +179,7 @@ __device__ __forceinline__ void closest_hit(const PtKernelParams& P, uint32_t* s
     for (;;) {
         while (cur >= 0) { // internal nodes: runs until every lane of the wave is at a leaf or finished
             if (COUNT) ++cn.nodes;
-            node_step<PT_BLOCK>(nodes, stack, o, inv, h.t, cur, sp);
+            node_step<PT_BLOCK, 0x7fffffff>(nodes, stack, nullptr, o, inv, h.t, cur, sp);
         }
         if (cur == PT_DONE) break;
         uint32_t code = ~(uint32_t)cur;
@@ -407,9 +447,14 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&P.counters->sched[24 + k], cn.cyc[k]);
     }
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long x = cn.depth[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters->sched[19 + k], x);
+    }
 }
 
-__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+__device__ __forceinline__ int popc64(unsigned long long m) { return (int)__builtin_popcountll(m); }
 // number of set bits of m below this lane
 __device__ __forceinline__ int rank_in(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
@@ -481,36 +526,72 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(const PtKernelParam
 // =====================================================================================================================
 //
 // Per-wave storage (DESIGN.md "data layout"):
-//   LDS    stack[level][lane]           the traversal stacks
+//   LDS    stack[level][lane]           top PT_LDS_STACK levels of the traversal stacks (deeper levels: HBM overflow columns)
 //          lray[field][slot]            L_DIR* ray direction; L_A* ray origin while the slot waits for / is in traversal,
 //                                       then the hit (u, v, triangle slot) once traversal has retired it
+//          lstate[field][slot]          S_*: the slot's pixel / path state, touched once per shading pass
 //          rayq / hitq / missq          ring buffers of slot ids (one byte each)
-//   HBM/L2 gstate[field][slot]          shading-only state of the slot's pixel and path (G_*), touched once per shading pass
-//          gpark[field][lane]           traversal registers of lanes interrupted by a phase switch
-// Keeping only what the traversal loop touches in LDS is what lets 16 waves share a CU's 160 KiB (the kernel is
-// latency-bound: measured time scales with 1/waves-per-CU).
+//   HBM/L2 park[field][lane]            traversal registers of lanes interrupted by a phase switch (7.8 MB chip-wide: L2 resident)
+//          ovf[level][lane]             stack levels >= PT_LDS_STACK
+// Round-1 history: with lstate in HBM (15 waves/CU) the slot state alone cost 1.3 TB of fabric traffic per C4 frame -- 60 % of
+// all L2 misses, at 70 % of the chip's measured random-64-B-gather rate (profiles/r01_fetch_calibration.md); with a full-depth
+// LDS stack and lstate in LDS only 8 waves fit a CU.  The short stack pays for keeping the state on chip.
 
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
 enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
-enum { G_PIX = 0, G_RNG, G_PACK, G_COLX, G_COLY, G_COLZ, G_THRX, G_THRY, G_THRZ, G_TICKET, G_QK, G_CHUNK, G_NFIELDS };
-// G_PACK: bits 0-15 sample index within the launch, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
+// S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = queue entry | chunk << 24
+enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
+// S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
-#define PT_FRESH 0xffffffffu // G_PIX marker: slot has no (pixel, chunk) running; G_TICKET then holds a ticket it waits on, or PT_FRESH
+#define PT_FRESH 0xffffffffu // S_PIX marker: slot has no (pixel, chunk) running; S_RNG then holds the ticket it waits on, or PT_FRESH
 enum { K_PSLOT = 0, K_CUR, K_SP, K_BT, K_BU, K_BV, K_BSLOT, K_BID, K_NFIELDS };
 
-static inline size_t pt_wave_lds_bytes(int stack_entries, int ns) { return ((size_t)stack_entries * PT_WAVE + (size_t)L_NFIELDS * ns) * 4 + (((size_t)3 * ns + 15) & ~(size_t)15); }
-static inline size_t pt_wave_state_words(int ns) { return (size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE; }
+static inline int pt_wave_lds_stack(int stack_entries) { return stack_entries < PT_LDS_STACK ? stack_entries : PT_LDS_STACK; }
+static inline size_t pt_wave_lds_bytes(int stack_entries, int ns)
+{
+    return ((size_t)pt_wave_lds_stack(stack_entries) * PT_WAVE + (size_t)(L_NFIELDS + S_NFIELDS) * ns) * 4 + (((size_t)3 * ns + 15) & ~(size_t)15);
+}
+static inline size_t pt_wave_state_words(int stack_entries)
+{
+    int ovf = stack_entries > PT_LDS_STACK ? stack_entries - PT_LDS_STACK : 0;
+    return (size_t)(K_NFIELDS + ovf) * PT_WAVE;
+}
 
 namespace {
 
 struct WaveCtx {
     uint32_t* lray;   // LDS
-    uint32_t PT_AS1* gstate; // global, this wave's region
+    uint32_t* lstate; // LDS
     uint8_t *rayq, *hitq, *missq;
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     __device__ __forceinline__ int wrap(int i) const { return i >= ns ? i - ns : i; } // i < 2 * ns
 };
+
+// Which shading pass the wave should run next (0: none -> traverse).  Used both at the top of the wave loop and as the exit test
+// of the traversal phase, so the two can never disagree (a disagreement is a livelock: leave traversal, shade nothing, re-enter).
+enum { PICK_NONE = 0, PICK_HIT = 1, PICK_MISS = 2 };
+__device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
+{
+    const bool miss_ok = !w.miss_blocked;
+    if (w.hit_count >= PT_WAVE) return PICK_HIT;
+    if (miss_ok && w.miss_count >= PT_WAVE) return PICK_MISS;
+    if (w.ray_count < PT_RAY_LOW) {
+        // the ray queue is about to run dry: a half-full shading pass is cheaper than idle traversal lanes (traversal is ~80 %
+        // of a wave's time, shading ~12 %)
+        const bool h = w.hit_count >= PT_MIN_BATCH, m = miss_ok && w.miss_count >= PT_MIN_BATCH;
+        if (h && (!m || w.hit_count >= w.miss_count)) return PICK_HIT;
+        if (m) return PICK_MISS;
+    }
+    if (starving) { // traversal has nothing to do: shade whatever is queued
+        if (w.hit_count > 0 && (w.hit_count >= w.miss_count || !miss_ok)) return PICK_HIT;
+        if (miss_ok && w.miss_count > 0) return PICK_MISS;
+    }
+    return PICK_NONE;
+}
 
 // One shading pass over up to 64 entries of the hit queue (IS_MISS = false) or the miss queue (IS_MISS = true):
 // device.cu:136-214 for the hit/miss, then sample accumulation, next camera ray / next pixel (device.cu:229-254).
@@ -519,7 +600,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 {
     const int ns = w.ns;
     uint32_t* lray = w.lray;
-    uint32_t PT_AS1* gstate = w.gstate;
+    uint32_t* gstate = w.lstate;
 #define LF(f, s) lray[(f) * ns + (s)]
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 #define GF(f, s) gstate[(f) * ns + (s)]
@@ -534,11 +615,12 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     bool to_ray = false, to_hit = false, to_wait = false, died = false;
     if (mine) {
         ps_slot = (int)q[w.wrap(q_head + lane)];
-        uint32_t pid = GF(G_PIX, ps_slot);
-        uint32_t ticket = GF(G_TICKET, ps_slot);
+        uint32_t pid = GF(S_PIX, ps_slot);
         const bool running = pid != PT_FRESH;
-        uint32_t qk = running ? GF(G_QK, ps_slot) : 0u, chunk = running ? GF(G_CHUNK, ps_slot) : 0u;
-        uint32_t pack = running ? GF(G_PACK, ps_slot) : 0u;
+        uint32_t ticket = running ? PT_FRESH : GF(S_RNG, ps_slot);
+        const uint32_t qkc = running ? GF(S_QKC, ps_slot) : 0u;
+        uint32_t qk = qkc & 0xffffffu, chunk = qkc >> 24;
+        uint32_t pack = running ? GF(S_PACK, ps_slot) : 0u;
         int s = (int)(pack & 0xffffu);
         PathState ps;
         ps.rng = 0; ps.org = vs(0.0f); ps.dir = vs(0.0f); ps.throughput = vs(1.0f); ps.depth = 0; ps.lobe = kLobeNone; ps.retries = 0;
@@ -547,10 +629,10 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         bool need_gen = !running;
         bool have_pixel = running;
         if (running) {
-            ps.rng = GF(G_RNG, ps_slot);
-            ps.throughput = V(GFF(G_THRX, ps_slot), GFF(G_THRY, ps_slot), GFF(G_THRZ, ps_slot));
-            color = V(GFF(G_COLX, ps_slot), GFF(G_COLY, ps_slot), GFF(G_COLZ, ps_slot));
-            px = (int)(pid & 0xffffu); // G_PIX holds x | y << 16
+            ps.rng = GF(S_RNG, ps_slot);
+            ps.throughput = V(GFF(S_THRX, ps_slot), GFF(S_THRY, ps_slot), GFF(S_THRZ, ps_slot));
+            color = V(GFF(S_COLX, ps_slot), GFF(S_COLY, ps_slot), GFF(S_COLZ, ps_slot));
+            px = (int)(pid & 0xffffu); // S_PIX holds x | y << 16
             py = (int)(pid >> 16);
             ps.depth = (int)((pack >> 16) & 63u);
             ps.lobe = (int)((pack >> 22) & 7u) - 1;
@@ -594,21 +676,20 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             }
         }
         if (!died) {
-            GF(G_TICKET, ps_slot) = ticket;
             if (to_wait) {
-                GF(G_PIX, ps_slot) = PT_FRESH;
+                GF(S_PIX, ps_slot) = PT_FRESH;
+                GF(S_RNG, ps_slot) = ticket;
             } else {
-                GF(G_PIX, ps_slot) = (uint32_t)px | ((uint32_t)py << 16);
-                GF(G_QK, ps_slot) = qk;
-                GF(G_CHUNK, ps_slot) = chunk;
-                GF(G_RNG, ps_slot) = ps.rng;
-                GF(G_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
-                GF(G_COLX, ps_slot) = __float_as_uint(color.x);
-                GF(G_COLY, ps_slot) = __float_as_uint(color.y);
-                GF(G_COLZ, ps_slot) = __float_as_uint(color.z);
-                GF(G_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
-                GF(G_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
-                GF(G_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
+                GF(S_PIX, ps_slot) = (uint32_t)px | ((uint32_t)py << 16);
+                GF(S_QKC, ps_slot) = qk | (chunk << 24);
+                GF(S_RNG, ps_slot) = ps.rng;
+                GF(S_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
+                GF(S_COLX, ps_slot) = __float_as_uint(color.x);
+                GF(S_COLY, ps_slot) = __float_as_uint(color.y);
+                GF(S_COLZ, ps_slot) = __float_as_uint(color.z);
+                GF(S_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
+                GF(S_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
+                GF(S_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
                 if (to_ray) {
                     LF(L_DIRX, ps_slot) = __float_as_uint(ps.dir.x);
                     LF(L_DIRY, ps_slot) = __float_as_uint(ps.dir.y);
@@ -650,15 +731,18 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const int ns = P.ns;
-    uint32_t* stack = lds + lane;                        // stack[level * 64]
-    uint32_t* lray = lds + P.stack_entries * PT_WAVE;    // lray[field * ns + slot]
-    uint32_t PT_AS1* gstate = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)G_NFIELDS * ns + (size_t)K_NFIELDS * PT_WAVE);
-    uint32_t PT_AS1* park = gstate + (size_t)G_NFIELDS * ns + lane; // park[field * 64]
+    const int lds_stack = P.stack_entries < PT_LDS_STACK ? P.stack_entries : PT_LDS_STACK;
+    uint32_t* stack = lds + lane;                   // stack[level * 64], levels < PT_LDS_STACK
+    uint32_t* lray = lds + lds_stack * PT_WAVE;     // lray[field * ns + slot]
+    uint32_t* lstate = lray + L_NFIELDS * ns;       // lstate[field * ns + slot]
+    const int ovf_levels = P.stack_entries > PT_LDS_STACK ? P.stack_entries - PT_LDS_STACK : 0;
+    uint32_t PT_AS1* park = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE) + lane; // park[field * 64]
+    uint32_t PT_AS1* ovf = park + K_NFIELDS * PT_WAVE;                                                                   // ovf[level * 64]
     WaveCtx w;
     w.lray = lray;
-    w.gstate = gstate;
+    w.lstate = lstate;
     w.ns = ns;
-    w.rayq = reinterpret_cast<uint8_t*>(lray + L_NFIELDS * ns);
+    w.rayq = reinterpret_cast<uint8_t*>(lstate + S_NFIELDS * ns);
     w.hitq = w.rayq + ns;
     w.missq = w.hitq + ns;
     const PtNode* __restrict__ nodes = P.nodes;
@@ -670,12 +754,12 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
     // every slot starts "fresh" (needs a pixel) and sits in the miss queue so that the first shading passes start them
     for (int i = lane; i < ns; i += PT_WAVE) {
         w.missq[i] = (uint8_t)i;
-        gstate[G_PIX * ns + i] = PT_FRESH;
-        gstate[G_TICKET * ns + i] = PT_FRESH;
+        lstate[S_PIX * ns + i] = PT_FRESH;
+        lstate[S_RNG * ns + i] = PT_FRESH;
     }
     w.miss_blocked = false;
     w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
-    int n_parked = 0;
+    int n_parked = 0, n_rounds = 0;
     Counters cn;
 
     unsigned long long t_begin = 0;
@@ -683,15 +767,20 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
     while (w.n_dead < ns) {
         unsigned long long t0 = 0;
         if (COUNT) t0 = __builtin_amdgcn_s_memtime();
-        const bool starving = w.ray_count == 0 && n_parked == 0; // traversal has nothing to do: shade whatever is queued
-        if (w.hit_count >= PT_WAVE || (starving && w.hit_count > 0 && (w.hit_count >= w.miss_count || w.miss_blocked))) {
+        const bool starving = w.ray_count == 0 && n_parked == 0;
+        const int pick = pick_pass(w, starving);
+        if (++n_rounds > PT_WATCHDOG_ROUNDS) { // scheduler bug guard: never hang the GPU
+            if (lane == 0) gp(P.error_flag)[0] = 1u;
+            break;
+        }
+        if (pick == PICK_HIT) {
             shade_pass<COUNT, false>(P, w, lane, cn);
             if (COUNT) cn.cyc[3] += __builtin_amdgcn_s_memtime() - t0;
-        } else if (!w.miss_blocked && (w.miss_count >= PT_WAVE || (starving && w.miss_count > 0))) {
+        } else if (pick == PICK_MISS) {
             shade_pass<COUNT, true>(P, w, lane, cn);
             if (COUNT) cn.cyc[4] += __builtin_amdgcn_s_memtime() - t0;
-        } else if (starving && w.hit_count == 0) {
-            // every live slot of this wave waits for a chunk that another wave is still rendering
+        } else if (starving) {
+            // every live slot of this wave waits for a work item that another wave is still rendering
             __builtin_amdgcn_s_sleep(64);
             w.miss_blocked = false;
             if (COUNT) { cn.sched[18] += 1; cn.cyc[6] += __builtin_amdgcn_s_memtime() - t0; }
@@ -723,7 +812,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
             if (COUNT) { t1 = __builtin_amdgcn_s_memtime(); cn.cyc[5] += t1 - t0; }
             for (;;) {
                 // idle lanes (pslot < 0) always hold cur == PT_DONE
-                const unsigned long long m_done = __ballot(cur == PT_DONE && pslot >= 0);
+                const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0);
                 const unsigned long long m_node = __ballot(cur >= 0);
                 const unsigned long long m_leaf = __ballot(cur < PT_DONE);
                 const int n_done = popc64(m_done);
@@ -773,7 +862,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     if (m_busy == 0ull) break;                                                           // nothing in flight
                     if (++n_retire_passes >= 16) w.miss_blocked = false; // time to poll the waiting tickets again
                     // a full shading batch is ready: go and turn it into rays (a miss queue that only holds unpublished tickets does not count)
-                    if (w.hit_count >= PT_WAVE || (!w.miss_blocked && w.miss_count >= PT_WAVE)) break;
+                    if (pick_pass(w, false) != PICK_NONE) break; // a shading batch is due: go and turn it into rays
                     continue;
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
@@ -782,7 +871,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
                     if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
-                        node_step<PT_WAVE>(nodes, stack, o, inv, h.t, cur, sp);
+                        node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
                     }
                     if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[0] += t2 - t1; t1 = t2; }
                 } else {
@@ -796,7 +885,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                             cur = (int)~(((uint32_t)(firstt + 1) << 3) | (uint32_t)(count - 1));
                         } else if (sp > 0) {
                             --sp;
-                            cur = (int)stack[sp * PT_WAVE];
+                            cur = (int)stack_pop<PT_WAVE, PT_LDS_STACK>(stack, ovf, sp);
                         } else {
                             cur = PT_DONE;
                         }
@@ -939,7 +1028,7 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         *block = PT_WAVE;
         *ns = n;
         *lds_bytes = pt_wave_lds_bytes(stack_entries, n);
-        *state_words_per_block = pt_wave_state_words(n);
+        *state_words_per_block = pt_wave_state_words(stack_entries);
     }
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, fn);

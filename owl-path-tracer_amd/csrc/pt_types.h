@@ -3,11 +3,13 @@
 #include <stdint.h>
 
 // One BVH2 node = both children's boxes + both child references: 64 bytes, 64-byte aligned,
-// fetched by one lane as 4 x global_load_dwordx4 (one half cache line).
+// fetched by one lane as 4 x global_load_dwordx4 (one half cache line).  The planes of the LEFT and RIGHT child are
+// interleaved pairwise -- lo[axis] = {left.min, right.min}, hi[axis] = {left.max, right.max} -- so that the slab test of both
+// children runs on packed f32 math (v_pk_add_f32 / v_pk_mul_f32: 12 instructions instead of 24).
 // child >= 0: index of an internal node.  child < 0: leaf, ~child = (first_slot << 3) | count (count 1..7).
 struct PtNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
+    float lo[3][2]; // lo[axis][0] = left child's min, lo[axis][1] = right child's min
+    float hi[3][2]; // hi[axis][0] = left child's max, hi[axis][1] = right child's max
     int32_t left, right;
     uint32_t pad[2];
 };
@@ -63,6 +65,7 @@ struct PtKernelParams {
     uint32_t* chunk_done;      // wavefront kernel: per queue entry, number of published spp chunks
     uint32_t* ring;            // wavefront kernel: FIFO of queue entries whose next chunk may start (n_pixels cells, lap-tagged)
     uint32_t* ring_tail;       // next ring position (starts at n_pixels)
+    uint32_t* error_flag;      // set to 1 by a wave whose scheduler watchdog fired
     PtTexDesc env_map;
     float cam[12];
     float env_color[3];

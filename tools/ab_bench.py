@@ -28,21 +28,32 @@ def main():
         c = sc["camera"]
         cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
     ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    if "shard_rank" in opts:
+        ctx.set_pixel_shard(int(opts["shard_rank"]), int(opts.get("shard_world", 8)), int(opts.get("shard_tile", 16)))
     for k, v in opts.items():
-        if k not in ("leaf_size", "max_bvh_depth", "spp", "census"):
+        if k not in ("leaf_size", "max_bvh_depth", "spp", "census", "shard_rank", "shard_world", "shard_tile"):
             ctx.set_option(k, int(v))
     ms = []
     for _ in range(reps):
         ctx.render(cam, W, H, spp, 16)
         ms.append(ctx.stats()["kernel_ms"])
     st = ctx.stats()
+    if opts.get("count"):
+        pass
+    if "shard_rank" in opts or opts.get("census"):
+        ctx.set_option("count", 1)
+        ctx.render(cam, W, H, spp, 16)
+        cs0 = ctx.stats()
+        ctx.set_option("count", 0)
+        print(json.dumps({"rays": cs0["rays"], "nodes": cs0["nodes"], "tris": cs0["tris"], "samples": cs0["samples"],
+                          "ns_per_ray": round(min(ms) * 1e6 / max(1, cs0["rays"]), 4), "ns_per_node": round(min(ms) * 1e6 / max(1, cs0["nodes"]), 5)}))
     if opts.get("census"):
         ctx.set_option("count", 1)
         ctx.render(cam, W, H, spp, 16)
         cs = ctx.stats()
         ctx.set_option("count", 0)
         sc = cs["sched"]
-        names = ["node_steps", "node_lanes", "tri_steps", "tri_lanes", "retire_passes", "retired", "hit_passes", "hit_items", "miss_passes", "miss_items", "winddown_iters", "winddown_idle", "iters", "idle_sum", "donewait_sum", "active_sum", "wait_polls", "passes_after_death", "sleeps"]
+        names = ["node_steps", "node_lanes", "tri_steps", "tri_lanes", "retire_passes", "retired", "hit_passes", "hit_items", "miss_passes", "miss_items", "winddown_iters", "winddown_idle", "iters", "idle_sum", "donewait_sum", "active_sum", "wait_polls", "passes_after_death", "sleeps", "pushes", "pushes_ge8", "pushes_ge12", "pushes_ge16"]
         cen = dict(zip(names, sc))
         cen.update({k: cs[k] for k in ("rays", "nodes", "tris", "scatters", "samples")})
         for a, b in (("node_lanes", "node_steps"), ("tri_lanes", "tri_steps"), ("retired", "retire_passes"), ("hit_items", "hit_passes"), ("miss_items", "miss_passes"), ("winddown_idle", "winddown_iters"), ("idle_sum", "iters"), ("donewait_sum", "iters"), ("active_sum", "iters")):
