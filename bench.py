@@ -46,6 +46,20 @@ def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
     return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
 
 
+def measured_traffic(world):
+    """HBM/fabric bytes per launch of the render kernel from rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE in
+    separate passes; FETCH_SIZE x 1024 is the byte count for this kernel's 64-byte gathers: profiles/r01_fetch_calibration.md).
+    PMC cannot be collected from inside the timed run, so the figure is read from the committed summary; null if absent/N>1."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return int(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def effective_cpus():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives 16 of 256)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -179,7 +193,7 @@ def main():
                        "kernel": "wavefront-scheduled megakernel, one persistent launch per frame", "chunk_spp": args.spp_per_launch or 64, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
                        "bvh_depth": int(st["bvh_depth"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
+                         "traffic": measured_traffic(world),
                          "kernel": "pt_render_wave_kernel<false>", "kernel_ms_per_launch": round(k_ms / launches, 3), "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": int(alg_bytes / launches),
                          "counts_per_frame_rank0": {k: int(cst[k]) for k in ("samples", "rays", "nodes", "tris", "scatters", "env_misses")},
