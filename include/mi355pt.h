@@ -145,6 +145,12 @@ int pt_debug_closest_hit_host(pt_ctx* ctx, const float org[3], const float dir[3
  * lets the parity tests compare them bit-for-bit with the oracle.  in/out are host arrays. */
 int pt_debug_eval(pt_ctx* ctx, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n);
 
+/* The pixel queue of the last pt_render* call with the cost-ordered schedule: queue_ids[i] = pixel id (x + width * y) of
+ * entry i of the cost-ordered queue, input_ids[i] / cost[i] = entry i of the shard's input queue and the rays its first
+ * prepass_spp samples traced (saturating at 255).  Any pointer may be NULL.  Returns the number of entries (0: the last
+ * render did not sort), or a negative error. */
+int64_t pt_debug_read_queue(pt_ctx* ctx, uint32_t* queue_ids, uint32_t* input_ids, uint8_t* cost, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelPa
                                        hipStream_t stream, int count);
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
+extern "C" size_t pt_sort_scratch_bytes(uint32_t n);
+extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch, hipStream_t stream);
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu);
 extern "C" int pt_debug_block(void);
@@ -58,7 +60,7 @@ struct pt_ctx {
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_chunk_done, d_ring, d_params;
+    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -68,10 +70,11 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 8, schedule = 1, prepass_spp = 8, heavy_waves_per_cu = 0, heavy_ns = 64, heavy_share = 3, census_mode = 0, sticky_pct = 75;
 
     pt_stats stats{};
     int last_launches = 0;
+    bool last_sorted = false;
 };
 
 namespace {
@@ -273,7 +276,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_chunk_done, &c->d_ring, &c->d_params};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -292,6 +295,14 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
+    else if (k == "heavy_waves_per_cu") c->heavy_waves_per_cu = (int)(value < 0 ? 0 : value);
+    else if (k == "heavy_ns") c->heavy_ns = (int)(value < 16 ? 16 : (value > 255 ? 255 : value));
+    else if (k == "heavy_share") c->heavy_share = (int)(value < 1 ? 1 : value);
+    else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? 1 : (value > 100 ? 100 : value));
+    else if (k == "census_mode") c->census_mode = (int)value;
+    else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
+    else if (k == "prepass_spp") c->prepass_spp = (int)(value < 1 ? 1 : (value > 15 ? 15 : value));
+    else if (k == "chunk_tail_min") c->chunk_tail_min = (int)(value < 0 ? 0 : (value > 65535 ? 65535 : value));
     else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
     else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
     else if (k == "kernel") {
@@ -454,27 +465,67 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
 
     // kernel 1 (lane-per-pixel): optional spp chunks = separate launches.  kernel 2 (wavefront): ONE persistent launch that
     // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
-    int S, n_launch, chunk = 0, n_chunks = 1;
+    // Chunk schedule of one wavefront launch over `total` samples per pixel: n_full chunks of `chunk` samples, then the rest in
+    // halving chunks (rem/2, rem/4, ... >= chunk_tail_min).  A frame ends when its slowest in-flight work item ends, so the
+    // last items must be short (profiles/r01_summary.md, "wind-down").
+    struct Schedule { int chunk = 0, n_full = 0, n_chunks = 1, tail_len[PT_MAX_TAIL_CHUNKS] = {}; };
+    auto make_schedule = [&](int total, int chunk, int rem_min) {
+        Schedule sc;
+        sc.chunk = std::max(1, std::min(chunk, total));
+        sc.n_full = total / sc.chunk;
+        int rem = total - sc.n_full * sc.chunk;
+        if (c->chunk_tail_min > 0 && sc.n_full > 0 && rem < rem_min) { --sc.n_full; rem += sc.chunk; }
+        int n_tail = 0;
+        while (rem > 0) {
+            int len = rem;
+            if (c->chunk_tail_min > 0 && rem > c->chunk_tail_min && n_tail < PT_MAX_TAIL_CHUNKS - 1) len = std::max(c->chunk_tail_min, (rem + 1) / 2);
+            sc.tail_len[n_tail++] = len;
+            rem -= len;
+        }
+        sc.n_chunks = sc.n_full + n_tail;
+        return sc;
+    };
+    // kernel 1 (lane-per-pixel): optional spp chunks = separate launches.
+    // Wavefront kernel, schedule 1 (default): a short cost pre-pass (prepass_spp samples of every pixel, rays counted), a
+    // counting sort of the pixel queue by that cost, then ONE persistent launch over the cost-ordered queue whose first chunk
+    // is sticky_pct % of the remaining samples (a slot keeps its pixel, no hand-offs, expensive pixels start first) and whose
+    // last samples go round in halving chunks through the per-chunk rings, so that the frame ends on ~n_pixels short work items.
+    // schedule 0 (or spp_per_launch, which the resumability tests use): one launch, chunk_spp chunks + halving tail.
+    // All schedules give the same image bit for bit (a pixel's stream does not depend on who renders it, or when).
+    int S, n_launch;
+    Schedule main_sc;
+    const bool sorted = c->kernel == 2 && c->schedule == 1 && c->spp_per_launch == 0 && max_samples >= 4 * c->prepass_spp && max_samples <= 65535;
     if (c->kernel == 1) {
         S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
         S = std::min(S, 65535);
         n_launch = (max_samples + S - 1) / S;
     } else {
-        chunk = std::min(c->spp_per_launch > 0 ? c->spp_per_launch : c->chunk_spp, std::min(max_samples, 65535));
-        n_chunks = (max_samples + chunk - 1) / chunk;
-        if ((uint64_t)c->n_pixels * (uint64_t)n_chunks >= 0xfffffff0ull) return fail(c, PT_E_LIMIT, "too many (pixel, chunk) tickets");
         S = max_samples;
-        n_launch = 1;
-        if (n_chunks > 255 || c->n_pixels >= (1u << 24)) return fail(c, PT_E_LIMIT, "ring tags need n_chunks <= 255 and < 2^24 pixels (raise chunk_spp)");
-        if ((rc = ensure(c, c->d_chunk_done, (size_t)c->n_pixels * 4))) return rc;
-        if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 + 8))) return rc; // cells + tail counter + watchdog flag
-        HIP_TRY(c, hipMemsetAsync(c->d_chunk_done.p, 0, (size_t)c->n_pixels * 4, stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4, stream));
-        HIP_TRY(c, hipMemcpyAsync((uint32_t*)c->d_ring.p + c->n_pixels, &c->n_pixels, 4, hipMemcpyHostToDevice, stream));
-        HIP_TRY(c, hipMemsetAsync((uint32_t*)c->d_ring.p + c->n_pixels + 1, 0, 4, stream));
+        n_launch = sorted ? 2 : 1;
+        if (sorted) {
+            const int rest = max_samples - c->prepass_spp;
+            const int big = std::max(1, (int)((int64_t)rest * c->sticky_pct / 100));
+            main_sc = make_schedule(rest, big, rest - big);
+            if ((rc = ensure(c, c->d_cost, (size_t)c->n_pixels))) return rc;
+            if ((rc = ensure(c, c->d_sorted, (size_t)c->n_pixels * 4))) return rc;
+            if ((rc = ensure(c, c->d_sort_scratch, pt_sort_scratch_bytes(c->n_pixels)))) return rc;
+        } else {
+            const int chunk = std::min(c->spp_per_launch > 0 ? c->spp_per_launch : c->chunk_spp, std::min(max_samples, 65535));
+            main_sc = make_schedule(max_samples, chunk, 1);
+        }
+        const int n_chunks = main_sc.n_chunks;
+        if ((uint64_t)c->n_pixels * (uint64_t)n_chunks >= 0xfff00000ull) return fail(c, PT_E_LIMIT, "too many (pixel, chunk) tickets");
+        if (n_chunks > 255 || c->n_pixels >= (1u << 24)) return fail(c, PT_E_LIMIT, "the wavefront kernel needs n_chunks <= 255 and < 2^24 pixels per rank (raise chunk_spp)");
+        // one ring of ready pixels per chunk index: ring c holds, in completion order of chunk c - 1, the pixels whose chunk c
+        // may start.  d_laps = watchdog flag + one fill counter per ring.
+        if ((rc = ensure(c, c->d_laps, (size_t)(n_chunks + 1) * 4))) return rc;
+        if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 * (size_t)n_chunks))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_laps.p, 0, (size_t)(n_chunks + 1) * 4, stream));
+        if (n_chunks > 1) HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4 * (size_t)n_chunks, stream));
     }
-    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 4))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 4, stream));
+    const int n_chunks = main_sc.n_chunks;
+    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 8))) return rc; // two ticket counters per launch
+    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 8, stream));
     HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
     if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
     if (n_launch > 1 || n_chunks > 1) {
@@ -500,19 +551,22 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.height = H;
     P.max_samples = max_samples;
     P.max_depth = max_depth;
-    P.chunk_done = (uint32_t*)c->d_chunk_done.p;
     P.ring = (uint32_t*)c->d_ring.p;
-    P.ring_tail = c->d_ring.p ? (uint32_t*)c->d_ring.p + c->n_pixels : nullptr;
-    P.error_flag = c->d_ring.p ? (uint32_t*)c->d_ring.p + c->n_pixels + 1 : nullptr;
-    P.chunk_spp = chunk;
+    P.ring_tail = c->d_laps.p ? (uint32_t*)c->d_laps.p + 1 : nullptr;
+    P.error_flag = (uint32_t*)c->d_laps.p;
+    P.cost_out = nullptr;
+    P.census_mode = c->census_mode;
+    P.chunk_spp = main_sc.chunk;
     P.n_chunks = n_chunks;
     P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
+    P.n_full = main_sc.n_full;
+    for (int i = 0; i < PT_MAX_TAIL_CHUNKS; ++i) P.tail_len[i] = main_sc.tail_len[i];
 
     // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 128; // 96..255 swept on C4 (profiles/r01_summary.md)
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 104; // largest count that still gives 16 waves/CU; 64..255 swept on C4 (profiles/r01_summary.md)
     HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
         // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
@@ -534,19 +588,49 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.ns = ns;
 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    if (c->kernel == 2 && (rc = ensure(c, c->d_params, sizeof(PtKernelParams) * (size_t)n_launch))) return rc;
     for (int l = 0; l < n_launch; ++l) {
-        P.queue_head = (uint32_t*)c->d_heads.p + l;
+        P.queue_head = (uint32_t*)c->d_heads.p + 2 * l;
+        P.heavy_end = 0;
+        P.n_heavy_blocks = 0;
+        P.heavy_ns = ns;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
-        if (c->kernel == 2) { // stream-ordered copy: the previous launch on this stream has finished reading the block
-            if ((rc = ensure(c, c->d_params, sizeof(PtKernelParams)))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->d_params.p, &P, sizeof(PtKernelParams), hipMemcpyHostToDevice, stream));
+        if (sorted) { // launch 0: cost pre-pass in queue order; launch 1: everything else, expensive pixels first
+            P.sample_begin = l == 0 ? 0 : c->prepass_spp;
+            P.sample_count = l == 0 ? c->prepass_spp : max_samples - c->prepass_spp;
+            P.pixel_ids = l == 0 ? (const uint32_t*)c->d_pixels.p : (const uint32_t*)c->d_sorted.p;
+            P.cost_out = l == 0 ? (uint8_t*)c->d_cost.p : nullptr;
+            if (l == 0) { // one chunk per pixel
+                P.chunk_spp = P.sample_count;
+                P.n_chunks = 1;
+                P.n_full = 1;
+                P.n_tickets = c->n_pixels;
+            } else {
+                P.chunk_spp = main_sc.chunk;
+                P.n_chunks = n_chunks;
+                P.n_full = main_sc.n_full;
+                P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
+            }
+            if (l == 1 && c->heavy_waves_per_cu > 0) {
+                P.n_heavy_blocks = std::min(grid, c->heavy_waves_per_cu * c->num_cus);
+                P.heavy_ns = std::min(ns, c->heavy_ns);
+                const uint64_t reserve = (uint64_t)P.n_heavy_blocks * (uint64_t)P.heavy_ns * (uint64_t)c->heavy_share;
+                P.heavy_end = (uint32_t)std::min<uint64_t>(reserve, c->n_pixels);
+                HIP_TRY(c, hipMemcpyAsync((uint32_t*)c->d_heads.p + 2 * l + 1, &P.heavy_end, 4, hipMemcpyHostToDevice, stream)); // counter 1 starts there
+            }
+            if (l == 1)
+                HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p, c->n_pixels,
+                                                 (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, stream));
         }
-        HIP_TRY(c, pt_launch_render(&P, (const PtKernelParams*)c->d_params.p, c->kernel, grid, lds, stream, c->count));
+        const PtKernelParams* dP = (const PtKernelParams*)c->d_params.p + l; // one block per launch: launch l+1's copy never races launch l
+        if (c->kernel == 2) HIP_TRY(c, hipMemcpyAsync((void*)dP, &P, sizeof(PtKernelParams), hipMemcpyHostToDevice, stream));
+        HIP_TRY(c, pt_launch_render(&P, dP, c->kernel, grid, lds, stream, c->count));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;
     c->last_launches = n_launch;
+    c->last_sorted = sorted;
     c->stats.vgprs = vg;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
@@ -578,7 +662,7 @@ int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max
     rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, nullptr);
     if (rc) return rc;
     uint32_t wd = 0;
-    if (c->kernel == 2 && c->d_ring.p) HIP_TRY(c, hipMemcpyAsync(&wd, (uint32_t*)c->d_ring.p + c->n_pixels + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->kernel == 2 && c->d_laps.p) HIP_TRY(c, hipMemcpyAsync(&wd, c->d_laps.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
     if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -646,6 +730,20 @@ int pt_debug_closest_hit_host(pt_ctx* c, const float org[3], const float dir[3],
 {
     if (!c || !c->have_scene) return PT_E_NO_SCENE;
     return pt_bvh_closest_hit_host(c->bvh, org, dir, tmin, tmax, t, u, v, prim) ? 1 : 0;
+}
+
+int64_t pt_debug_read_queue(pt_ctx* c, uint32_t* queue_ids, uint32_t* input_ids, uint8_t* cost, int64_t cap)
+{
+    if (!c) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_read_queue needs the GPU");
+    if (!c->last_sorted) return 0;
+    const int64_t n = std::min<int64_t>(cap, c->n_pixels);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (queue_ids) HIP_TRY(c, hipMemcpy(queue_ids, c->d_sorted.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (input_ids) HIP_TRY(c, hipMemcpy(input_ids, c->d_pixels.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cost) HIP_TRY(c, hipMemcpy(cost, c->d_cost.p, (size_t)n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 int pt_debug_eval(pt_ctx* c, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n)

@@ -42,6 +42,21 @@ using namespace ptd;
 #ifndef PT_MIN_BATCH
 #define PT_MIN_BATCH 32    // smallest shading batch taken early
 #endif
+#ifndef PT_SPECULATIVE
+#define PT_SPECULATIVE 1   // a lane that reaches a leaf stashes it (one pending leaf) and keeps walking nodes (Aila-Laine speculative traversal)
+#endif
+#ifndef PT_LEAF_WHOLE
+#define PT_LEAF_WHOLE 1  // a triangle step tests every triangle of the pending leaf (instead of one)
+#endif
+#ifndef PT_NODE_WAIT
+#define PT_NODE_WAIT 0
+#endif
+#ifndef PT_NODE_LO
+#define PT_NODE_LO 0   // hysteresis: stay on node steps until fewer than this many lanes want one (0 = plain majority vote)
+#endif
+#ifndef PT_LEAF_LO
+#define PT_LEAF_LO 0
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -132,7 +147,13 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
                                           int& sp, uint32_t* depth_census = nullptr)
 {
     const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode);
+#if PT_NODE_WAIT
+    f32x4 a = ldg4(nodes, nb);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); // experiment: let the line arrive before the 3 follow-up loads (no hit-on-miss in the TCP)
+    const f32x4 b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
+#else
     const f32x4 a = ldg4(nodes, nb), b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
+#endif
     const int chl = __float_as_int(chf.x), chr = __float_as_int(chf.y);
     // slab test of both children at once, {left, right} in the two halves of packed-f32 registers.  Same IEEE operations as
     // box_test: (bound - o) * inv, min/max ignoring NaN, far side scaled by 1.0000004.
@@ -334,7 +355,7 @@ __device__ __forceinline__ void finish_pixel(const PtKernelParams& P, uint32_t p
 // Next pixel of the queue: device.cu:224-228 (queue instead of a 2-D launch).  Returns false when exhausted.
 __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& pid, int& px, int& py, uint32_t& rng, v3& color)
 {
-    uint32_t q = atomicAdd(P.queue_head, 1u); // hipcc aggregates this into one atomic per wave
+    uint32_t q = atomicAdd(P.queue_head + 1, 1u); // hipcc aggregates this into one atomic per wave (counter 1: the whole queue, heavy_end is 0 here)
     if (q >= P.n_pixels) return false;
     pid = P.pixel_ids[q];
     px = (int)(pid % (uint32_t)P.width);
@@ -350,20 +371,34 @@ __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& p
 }
 
 // ---- (pixel, spp-chunk) work items of the wavefront kernel ----------------------------------------------------------------
-// The frame is cut into n_chunks chunks of chunk_spp samples per pixel.  A slot renders ONE chunk of a pixel, publishes the
-// pixel's (rng, accum) state and pushes the pixel onto a device-wide FIFO ring of "pixels whose next chunk may start"; then it
-// takes the next ticket.  Ticket t < n_pixels is chunk 0 of queue entry t (always ready); ticket t >= n_pixels is the
-// (t - n_pixels)-th pixel pushed onto the ring.  FIFO order makes all pixels advance at the same pace, so the end of the frame
-// still has ~n_pixels independent work items: with a slot keeping its pixel for all samples, 60 % of the scheduler iterations
-// ran in a wind-down with ~15 busy lanes; with chunk-major static tickets, slots spent 2.4 G polls waiting for predecessors.
+// Ring schedule: the frame is cut into n_chunks chunks per pixel (chunk_spp samples each, shrinking at the end).  A slot renders
+// ONE chunk c of a pixel, publishes the pixel's (rng, accum) state and appends the pixel to ring c + 1; then it takes the next
+// ticket.  Ticket t < n_pixels is chunk 0 of queue entry t (always ready); ticket t = c * n_pixels + i is the i-th pixel that
+// finished chunk c - 1.  Tickets are handed out in order, so every pixel finishes chunk c before the bulk of chunk c + 1 starts
+// and the end of the frame still has ~n_pixels independent work items.  A pixel whose chunk ran long lands at the END of the
+// next ring, where the ticket counter already waits for it: laggards are never queued behind faster pixels (a single FIFO
+// over all laps let expensive pixels fall ~20 ms further behind per lap; a slot keeping its pixel for all samples leaves
+// 25-28 % of the wave time to a wind-down with ~8 busy lanes - profiles/r01_summary.md).
 //
-// Cross-wave hand-off (MI355X_MICROARCH.md "Valid forms", sc1 row): the finishing lane stores the state and the chunk count with
-// agent-scope relaxed atomics (write-through sc1 stores), waits vmcnt(0), then takes a ring position and stores the tagged
+// Cross-wave hand-off (MI355X_MICROARCH.md "Valid forms", sc1 row): the finishing lane stores the state with
+// agent-scope relaxed atomics (write-through sc1 stores), waits vmcnt(0), then takes a ring position and stores the
 // entry (sc1).  The starting lane polls ITS ring cell with an sc1 load and only then issues the sc1 loads of the state (control
 // dependency).  No fence, no spinning: a slot whose cell is not published yet keeps its ticket and polls again in a later pass.
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(gp(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(gp(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#define PT_NO_TICKET 0xfffffffeu // take_ticket: the queue is exhausted
+// Next work item.  The queue has two ends: latency waves take [0, heavy_end) first (the most expensive pixels of the cost-ordered
+// queue), throughput waves take [heavy_end, n_tickets) first; whoever runs dry continues on the other range.  Counters may
+// overshoot their range by one take per slot.
+__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, bool heavy)
+{
+    uint32_t t = take_agent(P.queue_head + (heavy ? 0 : 1));
+    if (t < (heavy ? P.heavy_end : P.n_tickets)) return t;
+    t = take_agent(P.queue_head + (heavy ? 1 : 0));
+    return t < (heavy ? P.n_tickets : P.heavy_end) ? t : PT_NO_TICKET;
+}
 
 // Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
 __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& k, uint32_t& c, int& px, int& py, uint32_t& rng,
@@ -373,15 +408,15 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
         k = ticket;
         c = 0;
     } else {
-        const uint32_t e = ld_agent(P.ring + ticket % P.n_pixels);
-        if ((e >> 24) != ticket / P.n_pixels) return false; // tag = lap of the ring position (>= 1); cells start at 0
-        k = e & 0xffffffu;
-        c = ld_agent(P.chunk_done + k);
+        const uint32_t e = ld_agent(P.ring + ticket); // ring c = ticket / n_pixels, entry ticket % n_pixels
+        if (e == 0u) return false;                    // chunk c - 1 of that pixel is still running somewhere
+        k = e - 1u;
+        c = ticket / P.n_pixels;
     }
     const uint32_t pid = gp(P.pixel_ids)[k];
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
-    if (c == 0) {
+    if (c == 0 && P.sample_begin == 0) {
         rng = rng_init((uint32_t)px, (uint32_t)py); // device.cu:226
         color = vs(0.0f);
     } else {
@@ -394,14 +429,14 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
 
 __device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
 {
-    const int left = P.max_samples - (int)c * P.chunk_spp;
-    return left < P.chunk_spp ? left : P.chunk_spp;
+    return (int)c < P.n_full ? P.chunk_spp : P.tail_len[(int)c - P.n_full];
 }
 
 // The slot finished chunk c of queue entry k: write the framebuffer (device.cu:246-253) or hand the pixel on.
 __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k, uint32_t c, int px, int py, uint32_t rng, v3 color)
 {
-    if ((int)c + 1 >= P.n_chunks) {
+    const bool last_chunk = (int)c + 1 >= P.n_chunks;
+    if (last_chunk && P.sample_begin + P.sample_count >= P.max_samples) {
         v3 out = color * (1.0f / (float)P.max_samples);                          // device.cu:247
         size_t ofs = (size_t)px + (size_t)P.width * (size_t)(P.height - 1 - py); // device.cu:251
         float PT_AS1* orgb = gp(P.out_rgb);
@@ -416,10 +451,10 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k
         st_agent(a, __float_as_uint(color.x));
         st_agent(a + 1, __float_as_uint(color.y));
         st_agent(a + 2, __float_as_uint(color.z));
-        st_agent(P.chunk_done + k, c + 1);
+        if (last_chunk) return; // the next launch resumes the pixel (cost pre-pass -> main pass)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state has left this CU before the ring entry does
-        const uint32_t pos = take_agent(P.ring_tail); // starts at n_pixels
-        st_agent(P.ring + pos % P.n_pixels, k | ((pos / P.n_pixels) << 24));
+        const uint32_t pos = take_agent(P.ring_tail + (c + 1)); // completion order of chunk c = start order of chunk c + 1
+        st_agent(P.ring + (size_t)(c + 1) * P.n_pixels + pos, k + 1u);
     }
 }
 
@@ -546,7 +581,7 @@ enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ,
 // S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
 #define PT_FRESH 0xffffffffu // S_PIX marker: slot has no (pixel, chunk) running; S_RNG then holds the ticket it waits on, or PT_FRESH
-enum { K_PSLOT = 0, K_CUR, K_SP, K_BT, K_BU, K_BV, K_BSLOT, K_BID, K_NFIELDS };
+enum { K_PSLOT = 0, K_CUR, K_SP, K_BT, K_BU, K_BV, K_BSLOT, K_BID, K_PEND, K_NFIELDS };
 
 static inline int pt_wave_lds_stack(int stack_entries) { return stack_entries < PT_LDS_STACK ? stack_entries : PT_LDS_STACK; }
 static inline size_t pt_wave_lds_bytes(int stack_entries, int ns)
@@ -567,6 +602,7 @@ struct WaveCtx {
     uint8_t *rayq, *hitq, *missq;
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
+    bool heavy;        // latency wave: serves the expensive end of the cost-ordered queue
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     __device__ __forceinline__ int wrap(int i) const { return i >= ns ? i - ns : i; } // i < 2 * ns
 };
@@ -619,7 +655,8 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         const bool running = pid != PT_FRESH;
         uint32_t ticket = running ? PT_FRESH : GF(S_RNG, ps_slot);
         const uint32_t qkc = running ? GF(S_QKC, ps_slot) : 0u;
-        uint32_t qk = qkc & 0xffffffu, chunk = qkc >> 24;
+        // top byte of S_QKC: chunk index, or in the cost pre-pass (one chunk per pixel) the rays traced so far
+        uint32_t qk = qkc & 0xffffffu, chunk = P.cost_out ? 0u : qkc >> 24, cost = P.cost_out ? qkc >> 24 : 0u;
         uint32_t pack = running ? GF(S_PACK, ps_slot) : 0u;
         int s = (int)(pack & 0xffffu);
         PathState ps;
@@ -639,6 +676,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             ps.retries = (int)(pack >> 25);
             ps.dir = V(LFF(L_DIRX, ps_slot), LFF(L_DIRY, ps_slot), LFF(L_DIRZ, ps_slot));
             if (COUNT) ++cn.rays;
+            cost = cost < 255u ? cost + 1u : 255u;
             v3 radiance;
             const int tslot = IS_MISS ? -1 : (int)LF(L_AZ, ps_slot);
             int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
@@ -650,6 +688,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 ++s;
                 need_gen = true;
                 if (s == chunk_len(P, chunk)) {
+                    if (P.cost_out) { gp(P.cost_out)[qk] = (uint8_t)cost; cost = 0u; }
                     finish_chunk(P, qk, chunk, px, py, ps.rng, color);
                     have_pixel = false;
                     ticket = PT_FRESH;
@@ -660,8 +699,8 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = take_agent(P.queue_head); // hipcc aggregates this into one atomic per wave
-                if (ticket >= P.n_tickets) {
+                if (ticket == PT_FRESH) ticket = take_ticket(P, w.heavy); // hipcc aggregates each take into one atomic per wave
+                if (ticket == PT_NO_TICKET) {
                     died = true;
                 } else if (start_chunk(P, ticket, qk, chunk, px, py, ps.rng, color)) {
                     have_pixel = true;
@@ -681,7 +720,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 GF(S_RNG, ps_slot) = ticket;
             } else {
                 GF(S_PIX, ps_slot) = (uint32_t)px | ((uint32_t)py << 16);
-                GF(S_QKC, ps_slot) = qk | (chunk << 24);
+                GF(S_QKC, ps_slot) = qk | ((P.cost_out ? cost : chunk) << 24);
                 GF(S_RNG, ps_slot) = ps.rng;
                 GF(S_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
                 GF(S_COLX, ps_slot) = __float_as_uint(color.x);
@@ -711,7 +750,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     w.hit_count += popc64(m_hit);
     w.miss_count += popc64(m_wait);
     w.n_dead += popc64(m_dead);
-    if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? 1 : 0; }
+    if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? n : 0; } // [17]: rays shaded after the queue ran dry (wind-down)
     // a pass that only polled unpublished tickets must not be repeated before the wave has done something else
     w.miss_blocked = IS_MISS && n > 0 && popc64(m_wait) == n;
 #undef LF
@@ -752,21 +791,35 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 
     // every slot starts "fresh" (needs a pixel) and sits in the miss queue so that the first shading passes start them
-    for (int i = lane; i < ns; i += PT_WAVE) {
+    // Latency waves run fewer slots (a ray's turnaround is proportional to the slots sharing the wave) at raised issue priority:
+    // the pixels with the longest sample chains bound the frame time, not the throughput (profiles/r01_summary.md).
+    w.heavy = (int)blockIdx.x < P.n_heavy_blocks;
+    const int ns_live = w.heavy && P.heavy_ns < ns ? P.heavy_ns : ns;
+    if (w.heavy) __builtin_amdgcn_s_setprio(3);
+    for (int i = lane; i < ns_live; i += PT_WAVE) {
         w.missq[i] = (uint8_t)i;
         lstate[S_PIX * ns + i] = PT_FRESH;
         lstate[S_RNG * ns + i] = PT_FRESH;
     }
     w.miss_blocked = false;
-    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
+    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns_live; w.n_dead = ns - ns_live;
     int n_parked = 0, n_rounds = 0;
     Counters cn;
 
     unsigned long long t_begin = 0;
     if (COUNT) t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_dead = 0; // COUNT: when the first slot of this wave found the work queue exhausted
     while (w.n_dead < ns) {
         unsigned long long t0 = 0;
         if (COUNT) t0 = __builtin_amdgcn_s_memtime();
+        if (COUNT && w.n_dead > 0 && t_dead == 0) {
+            t_dead = t0;
+            if (P.census_mode == 1) { // census of the wind-down only
+                for (int k = 0; k < 7; ++k) cn.cyc[k] = 0;
+                for (int k = 0; k < 19; ++k) cn.sched[k] = 0;
+                cn.nodes = cn.tris = cn.rays = 0;
+            }
+        }
         const bool starving = w.ray_count == 0 && n_parked == 0;
         const int pick = pick_pass(w, starving);
         if (++n_rounds > PT_WATCHDOG_ROUNDS) { // scheduler bug guard: never hang the GPU
@@ -788,6 +841,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
             // ======================= TRAVERSAL PHASE ==============================================================
             int pslot = -1;
             int cur = PT_DONE, sp = 0;
+            int pend = PT_DONE; // pending leaf reference (< PT_DONE) or PT_DONE for none
             Hit h;
             h.t = kTMax; h.u = h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
             v3 o = vs(0.0f), d = vs(1.0f), inv = vs(1.0f);
@@ -801,20 +855,27 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     h.v = __uint_as_float(park[K_BV * PT_WAVE]);
                     h.slot = (int)park[K_BSLOT * PT_WAVE];
                     h.id = (int)park[K_BID * PT_WAVE];
+                    pend = (int)park[K_PEND * PT_WAVE];
                     o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
                     d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
                     inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 }
             }
             bool first = true;
+            bool mode_node = true;
             int n_retire_passes = 0;
             unsigned long long t1 = 0;
             if (COUNT) { t1 = __builtin_amdgcn_s_memtime(); cn.cyc[5] += t1 - t0; }
             for (;;) {
-                // idle lanes (pslot < 0) always hold cur == PT_DONE
+                // idle lanes (pslot < 0) always hold cur == PT_DONE and pend == PT_DONE
+#if PT_SPECULATIVE
+                const unsigned long long m_leaf = __ballot(pend < PT_DONE);               // lanes with a stashed leaf to test
+                const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0) & ~m_leaf;
+#else
                 const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0);
-                const unsigned long long m_node = __ballot(cur >= 0);
                 const unsigned long long m_leaf = __ballot(cur < PT_DONE);
+#endif
+                const unsigned long long m_node = __ballot(cur >= 0);
                 const int n_done = popc64(m_done);
                 if (COUNT) {
                     const int n_idle_c = popc64(__ballot(pslot < 0));
@@ -824,7 +885,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                 if (first || n_done >= PT_RETIRE_MIN || (m_node | m_leaf) == 0ull) {
                     first = false;
                     // ---- retire finished rays into the hit / miss queues (the hit overwrites the ray origin) ----
-                    const bool fin = pslot >= 0 && cur == PT_DONE;
+                    const bool fin = pslot >= 0 && cur == PT_DONE && pend == PT_DONE;
                     const bool fin_hit = fin && h.slot >= 0;
                     const bool fin_miss = fin && h.slot < 0;
                     const unsigned long long m_fh = __ballot(fin_hit), m_fm = __ballot(fin_miss);
@@ -852,6 +913,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                             inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                             cur = P.root;
                             sp = 0;
+                            pend = PT_DONE;
                             h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
                         }
                         w.ray_head = w.wrap(w.ray_head + take);
@@ -866,8 +928,72 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     continue;
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
-                // every iteration were measured 3-40 % slower, profiles/r01_sweeps.md) ----
-                if (popc64(m_node) >= popc64(m_leaf)) {
+                // every iteration were measured 3-40 % slower, profiles/r01_summary.md) ----
+                const int n_node = popc64(m_node), n_leaf = popc64(m_leaf);
+                if (PT_NODE_LO > 0) {
+                    if (mode_node) {
+                        if (n_node < PT_NODE_LO && n_leaf > n_node) mode_node = false;
+                    } else {
+                        if (n_leaf < PT_LEAF_LO && n_node >= n_leaf) mode_node = true;
+                    }
+                    if (n_leaf == 0) mode_node = true;
+                    if (n_node == 0) mode_node = false;
+                } else {
+                    mode_node = n_node >= n_leaf;
+                }
+#if PT_SPECULATIVE
+                // Speculative traversal: a lane arriving at a leaf stashes it in `pend` and keeps walking nodes; a second leaf blocks
+                // it (cur stays on that leaf) until a triangle step has drained `pend`.  Closest hit does not depend on visiting
+                // order (tie-break on triangle id), so this only changes which lanes are busy, not the result.
+                if (mode_node) {
+                    if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
+                    if (cur >= 0) {
+                        if (COUNT) ++cn.nodes;
+                        node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                        if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
+                            pend = cur;
+                            if (sp > 0) {
+                                --sp;
+                                cur = (int)stack_pop<PT_WAVE, PT_LDS_STACK>(stack, ovf, sp);
+                            } else {
+                                cur = PT_DONE;
+                            }
+                        }
+                    }
+                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[0] += t2 - t1; t1 = t2; }
+                } else {
+                    if (COUNT) { cn.sched[2] += 1; cn.sched[3] += popc64(m_leaf); }
+                    if (pend < PT_DONE) {
+                        uint32_t code = ~(uint32_t)pend;
+                        int firstt = (int)(code >> 3), count = (int)(code & 7u);
+#if PT_LEAF_WHOLE
+                        for (int k = 0; k < count; ++k) {
+                            if (COUNT) ++cn.tris;
+                            tri_test(tris, firstt + k, o, d, h);
+                        }
+                        count = 1;
+#else
+                        if (COUNT) ++cn.tris;
+                        tri_test(tris, firstt, o, d, h);
+#endif
+                        if (count > 1) {
+                            pend = (int)~(((uint32_t)(firstt + 1) << 3) | (uint32_t)(count - 1));
+                        } else if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
+                            pend = cur;
+                            if (sp > 0) {
+                                --sp;
+                                cur = (int)stack_pop<PT_WAVE, PT_LDS_STACK>(stack, ovf, sp);
+                            } else {
+                                cur = PT_DONE;
+                            }
+                        } else {
+                            pend = PT_DONE;
+                        }
+                    }
+                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[1] += t2 - t1; t1 = t2; }
+                }
+#else
+                if (mode_node) {
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
                     if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
@@ -892,6 +1018,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     }
                     if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[1] += t2 - t1; t1 = t2; }
                 }
+#endif
             }
             // ---- park unfinished traversals until the next traversal phase ----
             n_parked = popc64(__ballot(pslot >= 0));
@@ -905,13 +1032,18 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     park[K_BV * PT_WAVE] = __float_as_uint(h.v);
                     park[K_BSLOT * PT_WAVE] = (uint32_t)h.slot;
                     park[K_BID * PT_WAVE] = (uint32_t)h.id;
+                    park[K_PEND * PT_WAVE] = (uint32_t)pend;
                 }
             }
         }
     }
 #undef LF
 #undef LFF
-    if (COUNT) cn.cyc[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (COUNT) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        cn.cyc[7] = P.census_mode == 1 ? (t_dead ? t_end - t_dead : 0ull) : t_end - t_begin;
+        cn.sched[23] = t_dead ? (uint32_t)(t_end - t_dead) : 0u; // wind-down time of this wave
+    }
     flush_counters<COUNT>(P, cn);
 }
 
@@ -988,6 +1120,86 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
 // ---- launchers (called from pt_api.cpp) --------------------------------------------------------------------
 
 // d_params: device copy of *p (wavefront kernel reads its parameters from HBM; the caller keeps it stream-ordered)
+
+// ---- cost-ordered pixel queue ------------------------------------------------------------------------------------------
+// A pixel's samples are sequential (one RNG stream, device.cu:226-243), so a frame cannot end before its most expensive pixel
+// does.  The host runs a short pre-pass that records rays per pixel (cost_out), then these three kernels build a queue with
+// the expensive pixels first (stable counting sort over PT_SORT_BUCKETS cost classes, so neighbours stay neighbours).
+#define PT_SORT_BLOCK 256
+#define PT_SORT_ITEMS 16
+#define PT_SORT_BUCKETS 16
+
+__device__ __forceinline__ int cost_bucket(uint32_t cost, uint32_t c0)
+{
+    const uint32_t extra = cost > c0 ? cost - c0 : 0u; // every sample traces at least its camera ray
+    const uint32_t b = extra * 3u / c0;                // 3 classes per extra ray/sample; >= 6 rays/sample share the top class
+    return PT_SORT_BUCKETS - 1 - (int)(b < (uint32_t)(PT_SORT_BUCKETS - 1) ? b : (uint32_t)(PT_SORT_BUCKETS - 1)); // 0 = most expensive
+}
+
+__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8_t* __restrict__ cost, uint32_t n, uint32_t c0, uint32_t* __restrict__ block_hist)
+{
+    __shared__ uint32_t h[PT_SORT_BUCKETS];
+    if (threadIdx.x < PT_SORT_BUCKETS) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t first = (blockIdx.x * PT_SORT_BLOCK + threadIdx.x) * PT_SORT_ITEMS;
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) atomicAdd(&h[cost_bucket(cost[i], c0)], 1u);
+    __syncthreads();
+    if (threadIdx.x < PT_SORT_BUCKETS) block_hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of block_hist in (bucket, block) order; one workgroup
+__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scan_kernel(uint32_t* __restrict__ block_hist, uint32_t n_entries)
+{
+    __shared__ uint32_t part[PT_SORT_BLOCK];
+    const uint32_t per = (n_entries + PT_SORT_BLOCK - 1) / PT_SORT_BLOCK;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_entries ? lo + per : n_entries;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += block_hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < PT_SORT_BLOCK; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_hist[i]; block_hist[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scatter_kernel(const uint8_t* __restrict__ cost, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                       uint32_t n, uint32_t c0, const uint32_t* __restrict__ block_off)
+{
+    __shared__ uint32_t cnt[PT_SORT_BUCKETS][PT_SORT_BLOCK];
+    const uint32_t t = threadIdx.x;
+    for (int b = 0; b < PT_SORT_BUCKETS; ++b) cnt[b][t] = 0u;
+    const uint32_t first = (blockIdx.x * PT_SORT_BLOCK + t) * PT_SORT_ITEMS;
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) cnt[cost_bucket(cost[i], c0)][t] += 1u;
+    __syncthreads();
+    if (t < PT_SORT_BUCKETS) { // queue position of (bucket t, thread j) of this block
+        uint32_t run = block_off[t * gridDim.x + blockIdx.x];
+        for (int j = 0; j < PT_SORT_BLOCK; ++j) { const uint32_t v = cnt[t][j]; cnt[t][j] = run; run += v; }
+    }
+    __syncthreads();
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) out[cnt[cost_bucket(cost[i], c0)][t]++] = in[i];
+}
+
+extern "C" size_t pt_sort_scratch_bytes(uint32_t n)
+{
+    const uint32_t per_block = PT_SORT_BLOCK * PT_SORT_ITEMS;
+    return (size_t)((n + per_block - 1) / per_block) * PT_SORT_BUCKETS * sizeof(uint32_t);
+}
+
+extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch, hipStream_t stream)
+{
+    const uint32_t per_block = PT_SORT_BLOCK * PT_SORT_ITEMS;
+    const uint32_t nb = (n + per_block - 1) / per_block;
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_sort_hist_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, cost, n, c0, scratch);
+    hipLaunchKernelGGL(pt_sort_scan_kernel, dim3(1), dim3(PT_SORT_BLOCK), 0, stream, scratch, nb * PT_SORT_BUCKETS);
+    hipLaunchKernelGGL(pt_sort_scatter_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, cost, in, out, n, c0, (const uint32_t*)scratch);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
                                        hipStream_t stream, int count)
 {

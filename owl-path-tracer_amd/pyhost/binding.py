@@ -61,7 +61,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upload_scene", "pt_set_materials", "pt_set_environment",
            "pt_set_pixel_shard", "pt_shard_pixels", "pt_render", "pt_render_device", "pt_synchronize", "pt_set_option", "pt_get_stats",
-           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval"]
+           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue"]
 
 _lib = None
 
@@ -97,6 +97,8 @@ def lib():
     L.pt_to_camera_data.argtypes = [fp, fp, fp, C.c_float, C.c_int32, C.c_int32, C.POINTER(Camera)]
     L.pt_debug_closest_hit_host.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, fp, fp, fp, C.POINTER(C.c_int32)]
     L.pt_debug_eval.argtypes = [C.c_void_p, C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_int64]
+    L.pt_debug_read_queue.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_int64]
+    L.pt_debug_read_queue.restype = C.c_int64
     _lib = L
     return L
 
@@ -236,6 +238,15 @@ class Context:
         rc = self._check(lib().pt_debug_closest_hit_host(self._h, _vec3(org), _vec3(direction), tmin, tmax, C.byref(t), C.byref(u), C.byref(v),
                                                          C.byref(p)), "pt_debug_closest_hit_host")
         return bool(rc), float(t.value), float(u.value), float(v.value), int(p.value)
+
+    def read_queue(self, cap):
+        """(queue_ids, input_ids, cost) of the last cost-ordered render (empty arrays if it did not sort)."""
+        q = np.zeros(cap, np.uint32); i = np.zeros(cap, np.uint32); c = np.zeros(cap, np.uint8)
+        n = lib().pt_debug_read_queue(self._h, q.ctypes.data_as(C.POINTER(C.c_uint32)), i.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      c.ctypes.data_as(C.POINTER(C.c_uint8)), cap)
+        if n < 0:
+            self._check(int(n), "pt_debug_read_queue")
+        return q[:n], i[:n], c[:n]
 
     def debug_eval(self, op, inputs, out_stride):
         x = np.ascontiguousarray(inputs, np.float32)

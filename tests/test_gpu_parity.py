@@ -223,7 +223,7 @@ def test_cornell_image_bitwise_and_golden(gpu, orc, cornell):
     np.testing.assert_array_equal(rgba, want8)
     for k in ("samples", "rays", "scatters", "nan_retries"):
         assert st[k] == cnt[k], k
-    assert st["kernel_ms"] > 0 and st["launches"] == 1
+    assert st["kernel_ms"] > 0 and st["launches"] == 2  # cost pre-pass + main launch over the cost-ordered pixel queue
 
 
 def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
@@ -274,6 +274,21 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     assert gpu.stats()["launches"] == 1  # the wavefront kernel walks its (pixel, chunk) tickets inside one persistent launch
     gpu.set_option("spp_per_launch", 0)
     assert_bitwise(chunked, full, "chunked == single launch")
+    # the three schedules of the wavefront kernel give one image: cost-ordered queue (pre-pass + sort + main launch, default from
+    # 32 spp), FIFO ring of 64-spp tickets with a shrinking tail, ring with a fixed chunk
+    by_cost, _ = gpu.render(cam, W, H, 70, 16)
+    assert gpu.stats()["launches"] == 2
+    gpu.set_option("schedule", 0)
+    gpu.set_option("chunk_spp", 16)
+    ring, _ = gpu.render(cam, W, H, 70, 16)
+    assert gpu.stats()["launches"] == 1
+    gpu.set_option("chunk_tail_min", 0)
+    ring_fixed, _ = gpu.render(cam, W, H, 70, 16)
+    gpu.set_option("chunk_tail_min", 8)
+    gpu.set_option("chunk_spp", 64)
+    gpu.set_option("schedule", 1)
+    assert_bitwise(ring, by_cost, "FIFO ring == cost-ordered queue")
+    assert_bitwise(ring_fixed, by_cost, "fixed chunks == cost-ordered queue")
     # pixel-tile shards are disjoint: the sum over ranks (what the RCCL reduce computes) is the 1-GPU image bit-for-bit
     acc = np.zeros_like(full)
     for r in range(3):

@@ -18,7 +18,8 @@ def main():
             ctx.set_option(k, int(v))
     if which == "c4":
         _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "dragon.json"))
-        ents = scene_io.build_entities(procedural.dragon_standin(), mats)
+        du = int(opts.get("detail_u", 4357)); dv = int(opts.get("detail_v", 100))
+        ents = scene_io.build_entities(procedural.dragon_standin(du, dv), mats)
         W, H, spp = 1920, 1080, int(opts.get("spp", 1024))
         cam = B.to_camera_data([4, 2.5, 0], [0, .75, 0], [0, 1, 0], 50, W, H)
     else:
@@ -31,7 +32,7 @@ def main():
     if "shard_rank" in opts:
         ctx.set_pixel_shard(int(opts["shard_rank"]), int(opts.get("shard_world", 8)), int(opts.get("shard_tile", 16)))
     for k, v in opts.items():
-        if k not in ("leaf_size", "max_bvh_depth", "spp", "census", "shard_rank", "shard_world", "shard_tile"):
+        if k not in ("leaf_size", "max_bvh_depth", "spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v"):
             ctx.set_option(k, int(v))
     ms = []
     for _ in range(reps):
@@ -53,12 +54,14 @@ def main():
         cs = ctx.stats()
         ctx.set_option("count", 0)
         sc = cs["sched"]
-        names = ["node_steps", "node_lanes", "tri_steps", "tri_lanes", "retire_passes", "retired", "hit_passes", "hit_items", "miss_passes", "miss_items", "winddown_iters", "winddown_idle", "iters", "idle_sum", "donewait_sum", "active_sum", "wait_polls", "passes_after_death", "sleeps", "pushes", "pushes_ge8", "pushes_ge12", "pushes_ge16"]
+        names = ["node_steps", "node_lanes", "tri_steps", "tri_lanes", "retire_passes", "retired", "hit_passes", "hit_items", "miss_passes", "miss_items", "winddown_iters", "winddown_idle", "iters", "idle_sum", "donewait_sum", "active_sum", "wait_polls", "rays_after_death", "sleeps", "pushes", "pushes_ge8", "pushes_ge12", "pushes_ge16", "winddown_ticks"]
         cen = dict(zip(names, sc))
         cen.update({k: cs[k] for k in ("rays", "nodes", "tris", "scatters", "samples")})
         for a, b in (("node_lanes", "node_steps"), ("tri_lanes", "tri_steps"), ("retired", "retire_passes"), ("hit_items", "hit_passes"), ("miss_items", "miss_passes"), ("winddown_idle", "winddown_iters"), ("idle_sum", "iters"), ("donewait_sum", "iters"), ("active_sum", "iters")):
             cen[a + "/" + b] = round(cen[a] / max(1, cen[b]), 2)
         cyc = dict(zip(["node", "tri", "retire", "hit_pass", "miss_pass", "park_resume", "sleep", "total"], sc[24:32]))
+        cen["winddown_ray_share"] = round(cen["rays_after_death"] / max(1, cen["rays"]), 4)
+        cen["winddown_time_share"] = round(cen["winddown_ticks"] / max(1, cyc["total"]), 4)
         cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
         print(json.dumps(cen))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
