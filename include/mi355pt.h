@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 #define PT_MAT_FLOATS 17 /* material_data: device_global.hpp:19-36, 68 bytes, field order kept */
 
 enum {
@@ -78,7 +78,7 @@ typedef struct pt_camera {
 
 /* Work counters of the last counted render (pt_set_option "count" = 1). One sample = one camera path. */
 typedef struct pt_stats {
-    double kernel_ms;       /* sum of render-kernel durations of the last pt_render*, HIP events on the launch stream */
+    double kernel_ms;       /* first launch to last kernel end of the last pt_render*, HIP events on the launch stream */
     int32_t launches;       /* render-kernel launches in the last pt_render* */
     int32_t vgprs, sgprs, lds_bytes, block, grid, stack_entries; /* launch geometry of the render kernel */
     uint64_t samples, rays, nodes, tris, scatters, env_misses, nan_retries; /* valid when counted */
@@ -88,6 +88,7 @@ typedef struct pt_stats {
      * hit-shading passes, items, miss-shading passes, items, traversal phases, parked lanes,
      * scheduler iterations, sum of idle lanes, sum of finished lanes awaiting retirement, sum of node+leaf lanes} */
     uint64_t sched[32];
+    double prepass_ms;      /* part of kernel_ms spent in the cost pre-pass launch + queue sort (0 when the schedule has none) */
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
@@ -150,6 +151,11 @@ int pt_debug_eval(pt_ctx* ctx, int32_t op, const float* in, int32_t in_stride, f
  * prepass_spp samples traced (saturating at 255).  Any pointer may be NULL.  Returns the number of entries (0: the last
  * render did not sort), or a negative error. */
 int64_t pt_debug_read_queue(pt_ctx* ctx, uint32_t* queue_ids, uint32_t* input_ids, uint8_t* cost, int64_t cap);
+
+/* Timeline of the last wavefront launch, three arrays of n_chunks + 1 values: ticks[0] = constant 100 MHz clock (s_memrealtime)
+ * at kernel entry, ticks[1 + c] = when the last pixel finished chunk c; then [0] unused, [1 + c] = when the last work item of
+ * chunk c started; then [0] unused, [1 + c] = queue entry that finished chunk c last.  Returns the number of values written. */
+int64_t pt_debug_read_laps(pt_ctx* ctx, uint64_t* ticks, int64_t cap);
 
 #ifdef __cplusplus
 }

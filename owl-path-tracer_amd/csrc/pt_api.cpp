@@ -44,7 +44,7 @@ struct pt_ctx {
     bool host_only = false;
     int num_cus = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr; // evm: after the cost pre-pass and the queue sort
     bool ev_pending = false;
     std::string err;
 
@@ -70,11 +70,13 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 8, schedule = 1, prepass_spp = 8, heavy_waves_per_cu = 0, heavy_ns = 64, heavy_share = 3, census_mode = 0, sticky_pct = 75;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 50;
 
     pt_stats stats{};
     int last_launches = 0;
     bool last_sorted = false;
+    size_t lap_ticks_ofs = 0;
+    int last_chunks = 0;
 };
 
 namespace {
@@ -261,7 +263,7 @@ pt_ctx* pt_create(const pt_config* cfg)
     }
     c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "stream/event creation failed");
         delete c;
         return nullptr;
@@ -281,6 +283,7 @@ void pt_destroy(pt_ctx* c)
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->evm) (void)hipEventDestroy(c->evm);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -295,9 +298,6 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
-    else if (k == "heavy_waves_per_cu") c->heavy_waves_per_cu = (int)(value < 0 ? 0 : value);
-    else if (k == "heavy_ns") c->heavy_ns = (int)(value < 16 ? 16 : (value > 255 ? 255 : value));
-    else if (k == "heavy_share") c->heavy_share = (int)(value < 1 ? 1 : value);
     else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? 1 : (value > 100 ? 100 : value));
     else if (k == "census_mode") c->census_mode = (int)value;
     else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
@@ -518,14 +518,18 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         if (n_chunks > 255 || c->n_pixels >= (1u << 24)) return fail(c, PT_E_LIMIT, "the wavefront kernel needs n_chunks <= 255 and < 2^24 pixels per rank (raise chunk_spp)");
         // one ring of ready pixels per chunk index: ring c holds, in completion order of chunk c - 1, the pixels whose chunk c
         // may start.  d_laps = watchdog flag + one fill counter per ring.
-        if ((rc = ensure(c, c->d_laps, (size_t)(n_chunks + 1) * 4))) return rc;
+        // Layout (never a plain store in a cache line that also holds device-scope atomics): [0] watchdog flag | +256 B: ring fill
+        // counters (n_chunks + 1, + the pre-pass's spare) | 256-B aligned: diagnostics timelines of the two launches.
+        c->lap_ticks_ofs = ((256 + (size_t)(n_chunks + 3) * 4 + 255) / 256) * 256;
+        const size_t laps_bytes = c->lap_ticks_ofs + ((size_t)(n_chunks + 1) * 3 + 128) * 8 * 2;
+        if ((rc = ensure(c, c->d_laps, laps_bytes))) return rc;
         if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 * (size_t)n_chunks))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_laps.p, 0, (size_t)(n_chunks + 1) * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_laps.p, 0, laps_bytes, stream));
         if (n_chunks > 1) HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4 * (size_t)n_chunks, stream));
     }
     const int n_chunks = main_sc.n_chunks;
-    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 8))) return rc; // two ticket counters per launch
-    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 8, stream));
+    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 256))) return rc; // one ticket counter per launch, a cache line apart
+    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 256, stream));
     HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
     if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
     if (n_launch > 1 || n_chunks > 1) {
@@ -552,8 +556,10 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.max_samples = max_samples;
     P.max_depth = max_depth;
     P.ring = (uint32_t*)c->d_ring.p;
-    P.ring_tail = c->d_laps.p ? (uint32_t*)c->d_laps.p + 1 : nullptr;
+    P.ring_tail = c->d_laps.p ? (uint32_t*)c->d_laps.p + 64 : nullptr;
     P.error_flag = (uint32_t*)c->d_laps.p;
+    P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs);
+    c->last_chunks = n_chunks;
     P.cost_out = nullptr;
     P.census_mode = c->census_mode;
     P.chunk_spp = main_sc.chunk;
@@ -590,10 +596,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     if (c->kernel == 2 && (rc = ensure(c, c->d_params, sizeof(PtKernelParams) * (size_t)n_launch))) return rc;
     for (int l = 0; l < n_launch; ++l) {
-        P.queue_head = (uint32_t*)c->d_heads.p + 2 * l;
-        P.heavy_end = 0;
-        P.n_heavy_blocks = 0;
-        P.heavy_ns = ns;
+        P.queue_head = (uint32_t*)c->d_heads.p + 64 * l;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
         if (sorted) { // launch 0: cost pre-pass in queue order; launch 1: everything else, expensive pixels first
@@ -601,6 +604,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             P.sample_count = l == 0 ? c->prepass_spp : max_samples - c->prepass_spp;
             P.pixel_ids = l == 0 ? (const uint32_t*)c->d_pixels.p : (const uint32_t*)c->d_sorted.p;
             P.cost_out = l == 0 ? (uint8_t*)c->d_cost.p : nullptr;
+            P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs) + (l == 0 ? 3 * (n_chunks + 1) + 128 : 0);
+            P.ring_tail = (uint32_t*)c->d_laps.p + 64 + (l == 0 ? n_chunks : 0); // the pre-pass only uses its [1]: the spare counter
             if (l == 0) { // one chunk per pixel
                 P.chunk_spp = P.sample_count;
                 P.n_chunks = 1;
@@ -612,16 +617,11 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_full = main_sc.n_full;
                 P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
             }
-            if (l == 1 && c->heavy_waves_per_cu > 0) {
-                P.n_heavy_blocks = std::min(grid, c->heavy_waves_per_cu * c->num_cus);
-                P.heavy_ns = std::min(ns, c->heavy_ns);
-                const uint64_t reserve = (uint64_t)P.n_heavy_blocks * (uint64_t)P.heavy_ns * (uint64_t)c->heavy_share;
-                P.heavy_end = (uint32_t)std::min<uint64_t>(reserve, c->n_pixels);
-                HIP_TRY(c, hipMemcpyAsync((uint32_t*)c->d_heads.p + 2 * l + 1, &P.heavy_end, 4, hipMemcpyHostToDevice, stream)); // counter 1 starts there
-            }
-            if (l == 1)
+            if (l == 1) {
                 HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p, c->n_pixels,
                                                  (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, stream));
+                HIP_TRY(c, hipEventRecord(c->evm, stream));
+            }
         }
         const PtKernelParams* dP = (const PtKernelParams*)c->d_params.p + l; // one block per launch: launch l+1's copy never races launch l
         if (c->kernel == 2) HIP_TRY(c, hipMemcpyAsync((void*)dP, &P, sizeof(PtKernelParams), hipMemcpyHostToDevice, stream));
@@ -679,6 +679,11 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.kernel_ms = ms;
+        c->stats.prepass_ms = 0.0;
+        if (c->last_sorted) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->evm));
+            c->stats.prepass_ms = ms;
+        }
         c->stats.launches = c->last_launches;
         c->ev_pending = false;
         if (c->count && c->d_counters.p) {
@@ -743,6 +748,18 @@ int64_t pt_debug_read_queue(pt_ctx* c, uint32_t* queue_ids, uint32_t* input_ids,
     if (queue_ids) HIP_TRY(c, hipMemcpy(queue_ids, c->d_sorted.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (input_ids) HIP_TRY(c, hipMemcpy(input_ids, c->d_pixels.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (cost) HIP_TRY(c, hipMemcpy(cost, c->d_cost.p, (size_t)n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int64_t pt_debug_read_laps(pt_ctx* c, uint64_t* ticks, int64_t cap)
+{
+    if (!c || !ticks) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_read_laps needs the GPU");
+    if (c->kernel != 2 || !c->d_laps.p) return 0;
+    const int64_t n = std::min<int64_t>(cap, 3 * (c->last_chunks + 1) + 128);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(ticks, (char*)c->d_laps.p + c->lap_ticks_ofs, (size_t)n * 8, hipMemcpyDeviceToHost));
     return n;
 }
 

@@ -42,21 +42,6 @@ using namespace ptd;
 #ifndef PT_MIN_BATCH
 #define PT_MIN_BATCH 32    // smallest shading batch taken early
 #endif
-#ifndef PT_SPECULATIVE
-#define PT_SPECULATIVE 1   // a lane that reaches a leaf stashes it (one pending leaf) and keeps walking nodes (Aila-Laine speculative traversal)
-#endif
-#ifndef PT_LEAF_WHOLE
-#define PT_LEAF_WHOLE 1  // a triangle step tests every triangle of the pending leaf (instead of one)
-#endif
-#ifndef PT_NODE_WAIT
-#define PT_NODE_WAIT 0
-#endif
-#ifndef PT_NODE_LO
-#define PT_NODE_LO 0   // hysteresis: stay on node steps until fewer than this many lanes want one (0 = plain majority vote)
-#endif
-#ifndef PT_LEAF_LO
-#define PT_LEAF_LO 0
-#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -147,13 +132,7 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
                                           int& sp, uint32_t* depth_census = nullptr)
 {
     const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode);
-#if PT_NODE_WAIT
-    f32x4 a = ldg4(nodes, nb);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); // experiment: let the line arrive before the 3 follow-up loads (no hit-on-miss in the TCP)
-    const f32x4 b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
-#else
     const f32x4 a = ldg4(nodes, nb), b = ldg4(nodes, nb + 16), c = ldg4(nodes, nb + 32), chf = ldg4(nodes, nb + 48);
-#endif
     const int chl = __float_as_int(chf.x), chr = __float_as_int(chf.y);
     // slab test of both children at once, {left, right} in the two halves of packed-f32 registers.  Same IEEE operations as
     // box_test: (bound - o) * inv, min/max ignoring NaN, far side scaled by 1.0000004.
@@ -355,7 +334,7 @@ __device__ __forceinline__ void finish_pixel(const PtKernelParams& P, uint32_t p
 // Next pixel of the queue: device.cu:224-228 (queue instead of a 2-D launch).  Returns false when exhausted.
 __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& pid, int& px, int& py, uint32_t& rng, v3& color)
 {
-    uint32_t q = atomicAdd(P.queue_head + 1, 1u); // hipcc aggregates this into one atomic per wave (counter 1: the whole queue, heavy_end is 0 here)
+    uint32_t q = atomicAdd(P.queue_head, 1u); // hipcc aggregates this into one atomic per wave
     if (q >= P.n_pixels) return false;
     pid = P.pixel_ids[q];
     px = (int)(pid % (uint32_t)P.width);
@@ -389,15 +368,11 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic
 __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define PT_NO_TICKET 0xfffffffeu // take_ticket: the queue is exhausted
-// Next work item.  The queue has two ends: latency waves take [0, heavy_end) first (the most expensive pixels of the cost-ordered
-// queue), throughput waves take [heavy_end, n_tickets) first; whoever runs dry continues on the other range.  Counters may
-// overshoot their range by one take per slot.
-__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, bool heavy)
+// Next work item: tickets are handed out in order (hipcc aggregates the per-lane atomics of a pass into one per wave).
+__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P)
 {
-    uint32_t t = take_agent(P.queue_head + (heavy ? 0 : 1));
-    if (t < (heavy ? P.heavy_end : P.n_tickets)) return t;
-    t = take_agent(P.queue_head + (heavy ? 1 : 0));
-    return t < (heavy ? P.n_tickets : P.heavy_end) ? t : PT_NO_TICKET;
+    const uint32_t t = take_agent(P.queue_head);
+    return t < P.n_tickets ? t : PT_NO_TICKET;
 }
 
 // Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
@@ -413,6 +388,7 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
         k = e - 1u;
         c = ticket / P.n_pixels;
     }
+    if (ticket % P.n_pixels == P.n_pixels - 1u) gp(P.lap_ticks)[(P.n_chunks + 1) + 1 + c] = wall_clock64(); // last start of chunk c
     const uint32_t pid = gp(P.pixel_ids)[k];
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
@@ -436,6 +412,12 @@ __device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
 __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k, uint32_t c, int px, int py, uint32_t rng, v3 color)
 {
     const bool last_chunk = (int)c + 1 >= P.n_chunks;
+    if (last_chunk) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
+        if (take_agent(P.ring_tail + P.n_chunks) == P.n_pixels - 1u) {
+            gp(P.lap_ticks)[P.n_chunks] = wall_clock64();
+            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + P.n_chunks] = k;
+        }
+    }
     if (last_chunk && P.sample_begin + P.sample_count >= P.max_samples) {
         v3 out = color * (1.0f / (float)P.max_samples);                          // device.cu:247
         size_t ofs = (size_t)px + (size_t)P.width * (size_t)(P.height - 1 - py); // device.cu:251
@@ -455,6 +437,10 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state has left this CU before the ring entry does
         const uint32_t pos = take_agent(P.ring_tail + (c + 1)); // completion order of chunk c = start order of chunk c + 1
         st_agent(P.ring + (size_t)(c + 1) * P.n_pixels + pos, k + 1u);
+        if (pos == P.n_pixels - 1u) {
+            gp(P.lap_ticks)[c + 1] = wall_clock64();
+            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + c + 1] = k;
+        }
     }
 }
 
@@ -602,7 +588,6 @@ struct WaveCtx {
     uint8_t *rayq, *hitq, *missq;
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
-    bool heavy;        // latency wave: serves the expensive end of the cost-ordered queue
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     __device__ __forceinline__ int wrap(int i) const { return i >= ns ? i - ns : i; } // i < 2 * ns
 };
@@ -699,7 +684,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = take_ticket(P, w.heavy); // hipcc aggregates each take into one atomic per wave
+                if (ticket == PT_FRESH) ticket = take_ticket(P);
                 if (ticket == PT_NO_TICKET) {
                     died = true;
                 } else if (start_chunk(P, ticket, qk, chunk, px, py, ps.rng, color)) {
@@ -791,18 +776,13 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 
     // every slot starts "fresh" (needs a pixel) and sits in the miss queue so that the first shading passes start them
-    // Latency waves run fewer slots (a ray's turnaround is proportional to the slots sharing the wave) at raised issue priority:
-    // the pixels with the longest sample chains bound the frame time, not the throughput (profiles/r01_summary.md).
-    w.heavy = (int)blockIdx.x < P.n_heavy_blocks;
-    const int ns_live = w.heavy && P.heavy_ns < ns ? P.heavy_ns : ns;
-    if (w.heavy) __builtin_amdgcn_s_setprio(3);
-    for (int i = lane; i < ns_live; i += PT_WAVE) {
+    for (int i = lane; i < ns; i += PT_WAVE) {
         w.missq[i] = (uint8_t)i;
         lstate[S_PIX * ns + i] = PT_FRESH;
         lstate[S_RNG * ns + i] = PT_FRESH;
     }
     w.miss_blocked = false;
-    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns_live; w.n_dead = ns - ns_live;
+    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
     int n_parked = 0, n_rounds = 0;
     Counters cn;
 
@@ -862,19 +842,13 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                 }
             }
             bool first = true;
-            bool mode_node = true;
             int n_retire_passes = 0;
             unsigned long long t1 = 0;
             if (COUNT) { t1 = __builtin_amdgcn_s_memtime(); cn.cyc[5] += t1 - t0; }
             for (;;) {
                 // idle lanes (pslot < 0) always hold cur == PT_DONE and pend == PT_DONE
-#if PT_SPECULATIVE
                 const unsigned long long m_leaf = __ballot(pend < PT_DONE);               // lanes with a stashed leaf to test
                 const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0) & ~m_leaf;
-#else
-                const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0);
-                const unsigned long long m_leaf = __ballot(cur < PT_DONE);
-#endif
                 const unsigned long long m_node = __ballot(cur >= 0);
                 const int n_done = popc64(m_done);
                 if (COUNT) {
@@ -929,23 +903,10 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
                 // every iteration were measured 3-40 % slower, profiles/r01_summary.md) ----
-                const int n_node = popc64(m_node), n_leaf = popc64(m_leaf);
-                if (PT_NODE_LO > 0) {
-                    if (mode_node) {
-                        if (n_node < PT_NODE_LO && n_leaf > n_node) mode_node = false;
-                    } else {
-                        if (n_leaf < PT_LEAF_LO && n_node >= n_leaf) mode_node = true;
-                    }
-                    if (n_leaf == 0) mode_node = true;
-                    if (n_node == 0) mode_node = false;
-                } else {
-                    mode_node = n_node >= n_leaf;
-                }
-#if PT_SPECULATIVE
-                // Speculative traversal: a lane arriving at a leaf stashes it in `pend` and keeps walking nodes; a second leaf blocks
-                // it (cur stays on that leaf) until a triangle step has drained `pend`.  Closest hit does not depend on visiting
-                // order (tie-break on triangle id), so this only changes which lanes are busy, not the result.
-                if (mode_node) {
+                // Speculative traversal (Aila-Laine): a lane arriving at a leaf stashes it in `pend` and keeps walking nodes; a second
+                // leaf blocks it (cur stays on that leaf) until a triangle step has drained `pend`.  Closest hit does not depend on
+                // visiting order (tie-break on triangle id), so this only changes which lanes are busy, not the result.
+                if (popc64(m_node) >= popc64(m_leaf)) {
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
                     if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
@@ -963,22 +924,14 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[0] += t2 - t1; t1 = t2; }
                 } else {
                     if (COUNT) { cn.sched[2] += 1; cn.sched[3] += popc64(m_leaf); }
-                    if (pend < PT_DONE) {
-                        uint32_t code = ~(uint32_t)pend;
-                        int firstt = (int)(code >> 3), count = (int)(code & 7u);
-#if PT_LEAF_WHOLE
+                    if (pend < PT_DONE) { // every triangle of the pending leaf in one step: the leaf lanes are cleared for good
+                        const uint32_t code = ~(uint32_t)pend;
+                        const int firstt = (int)(code >> 3), count = (int)(code & 7u);
                         for (int k = 0; k < count; ++k) {
                             if (COUNT) ++cn.tris;
                             tri_test(tris, firstt + k, o, d, h);
                         }
-                        count = 1;
-#else
-                        if (COUNT) ++cn.tris;
-                        tri_test(tris, firstt, o, d, h);
-#endif
-                        if (count > 1) {
-                            pend = (int)~(((uint32_t)(firstt + 1) << 3) | (uint32_t)(count - 1));
-                        } else if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
+                        if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
                             pend = cur;
                             if (sp > 0) {
                                 --sp;
@@ -992,33 +945,6 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                     }
                     if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[1] += t2 - t1; t1 = t2; }
                 }
-#else
-                if (mode_node) {
-                    if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
-                    if (cur >= 0) {
-                        if (COUNT) ++cn.nodes;
-                        node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
-                    }
-                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[0] += t2 - t1; t1 = t2; }
-                } else {
-                    if (COUNT) { cn.sched[2] += 1; cn.sched[3] += popc64(m_leaf); }
-                    if (cur < PT_DONE) {
-                        uint32_t code = ~(uint32_t)cur;
-                        int firstt = (int)(code >> 3), count = (int)(code & 7u);
-                        if (COUNT) ++cn.tris;
-                        tri_test(tris, firstt, o, d, h);
-                        if (count > 1) {
-                            cur = (int)~(((uint32_t)(firstt + 1) << 3) | (uint32_t)(count - 1));
-                        } else if (sp > 0) {
-                            --sp;
-                            cur = (int)stack_pop<PT_WAVE, PT_LDS_STACK>(stack, ovf, sp);
-                        } else {
-                            cur = PT_DONE;
-                        }
-                    }
-                    if (COUNT) { unsigned long long t2 = __builtin_amdgcn_s_memtime(); cn.cyc[1] += t2 - t1; t1 = t2; }
-                }
-#endif
             }
             // ---- park unfinished traversals until the next traversal phase ----
             n_parked = popc64(__ballot(pslot >= 0));

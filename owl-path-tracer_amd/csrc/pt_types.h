@@ -57,7 +57,7 @@ struct PtKernelParams {
     const float* materials; // n_materials * PT_MAT_STRIDE
     const PtTexDesc* textures;
     const uint32_t* pixel_ids; // work queue: launch-index pixel ids owned by this context
-    uint32_t* queue_head;      // two counters per launch: [0] walks tickets [0, heavy_end), [1] walks [heavy_end, n_tickets)
+    uint32_t* queue_head;      // ticket counter, one per launch
     uint32_t* rng_state;       // per pixel (launch-index order), carried between spp chunks
     float* accum;              // per pixel * 3, carried between spp chunks
     float* out_rgb;            // W*H*3, framebuffer order
@@ -66,6 +66,7 @@ struct PtKernelParams {
     uint32_t* slot_state;      // wavefront kernel: per-wave path-slot state + park area (pt_wave_state_words each)
     uint32_t* ring;            // wavefront kernel: ring[c * n_pixels + i] = 1 + queue entry whose chunk c may start (0: not yet), in completion order of chunk c - 1
     uint32_t* ring_tail;       // ring_tail[c] = entries published to ring c so far
+    unsigned long long* lap_ticks; // [0] = s_memrealtime (100 MHz) at kernel entry, [c + 1] = when the last pixel finished chunk c (diagnostics)
     uint32_t* error_flag;      // set to 1 by a wave whose scheduler watchdog fired
     uint8_t* cost_out;         // cost pre-pass only (n_chunks == 1): rays traced per queue entry, saturating at 255
     PtTexDesc env_map;
@@ -85,9 +86,6 @@ struct PtKernelParams {
     int32_t ns;                // wavefront kernel: path slots per wave (64..255)
     int32_t chunk_spp, n_chunks; // wavefront kernel: samples per (pixel, chunk) ticket and chunks per pixel
     uint32_t n_tickets;        // n_pixels * n_chunks
-    uint32_t heavy_end;        // cost-ordered queue: entries [0, heavy_end) are reserved for the latency waves (0: none)
-    int32_t n_heavy_blocks;    // workgroups [0, n_heavy_blocks) are latency waves: heavy_ns slots, raised wave priority
-    int32_t heavy_ns;
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];

@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("block", C.c_int32), ("grid", C.c_int32), ("stack_entries", C.c_int32),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("scatters", C.c_uint64),
                 ("env_misses", C.c_uint64), ("nan_retries", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32)]
+                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -61,7 +61,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upload_scene", "pt_set_materials", "pt_set_environment",
            "pt_set_pixel_shard", "pt_shard_pixels", "pt_render", "pt_render_device", "pt_synchronize", "pt_set_option", "pt_get_stats",
-           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue"]
+           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps"]
 
 _lib = None
 
@@ -99,6 +99,8 @@ def lib():
     L.pt_debug_eval.argtypes = [C.c_void_p, C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_int64]
     L.pt_debug_read_queue.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_int64]
     L.pt_debug_read_queue.restype = C.c_int64
+    L.pt_debug_read_laps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
+    L.pt_debug_read_laps.restype = C.c_int64
     _lib = L
     return L
 
@@ -247,6 +249,16 @@ class Context:
         if n < 0:
             self._check(int(n), "pt_debug_read_queue")
         return q[:n], i[:n], c[:n]
+
+    def read_laps(self):
+        """ms since kernel entry at which the last pixel finished chunk 0, 1, ... of the last wavefront launch."""
+        t = np.zeros(3 * 257 + 128, np.uint64)
+        n = lib().pt_debug_read_laps(self._h, t.ctypes.data_as(C.POINTER(C.c_uint64)), t.size)
+        if n < 0:
+            self._check(int(n), "pt_debug_read_laps")
+        m = (int(n) - 128) // 3
+        ms = lambda x: round((int(x) - int(t[0])) / 1e5, 2)
+        return {"last_done_ms": [ms(x) for x in t[1:m]], "last_start_ms": [ms(x) for x in t[m + 1:2 * m]], "last_entry": [int(x) for x in t[2 * m + 1:3 * m]]}
 
     def debug_eval(self, op, inputs, out_stride):
         x = np.ascontiguousarray(inputs, np.float32)
