@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a tools/profile_round.sh run into profiles/: python tools/publish_profile.py gpurun_out/prof_<tag> <name>"""
+import csv, json, os, shutil, sys
+
+src, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, name + "_kernel_stats.csv"))
+with open(os.path.join(src, "bench.log")) as f:
+    lines = [l for l in f if l.startswith("{")]
+with open(os.path.join(dst, name + "_bench.log"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1   (the JSON line bench.py printed under the profiler)\n")
+    f.write(lines[-1])
+bench = json.loads(lines[-1])
+# per-launch durations of the render kernel from the kernel trace of the same run
+rows = []
+with open(os.path.join(src, "kernel_trace.csv")) as f:
+    for r in csv.DictReader(f):
+        if "pt_render_wave_kernel" in r["Kernel_Name"] or "pt_sort" in r["Kernel_Name"]:
+            rows.append((r["Kernel_Name"].split("(")[0], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+with open(os.path.join(dst, name + "_kernel_trace.txt"), "w") as f:
+    f.write("# kernel, duration ms, in launch order (same run as %s_kernel_stats.csv): <true> = counted render bench.py does once for the\n"
+            "# algorithmic byte counts; per frame <false> runs twice: cost pre-pass (8 spp) then the main launch\n" % name)
+    for k, ms in rows:
+        f.write("%s %.3f\n" % (k, ms))
+pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
+pmc["command"] = "rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (tools/profile_round.sh)"
+json.dump(pmc, open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
+d = pmc["derived"]
+traffic = {
+    "round": 1, "kernel": "pt_render_wave_kernel<false>, main launch (2nd of 2 per frame)",
+    "workload": "C4 dragon stand-in 1920x1080x1024spp depth 16, 1 GPU",
+    "command": pmc["command"] + "; FETCH_SIZE and WRITE_SIZE in separate passes",
+    "FETCH_SIZE_KB": pmc["counters_per_main_launch"]["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["counters_per_main_launch"]["WRITE_SIZE"],
+    "correction": "FETCH_SIZE x 1024 = bytes for this kernel's per-lane 64-byte gathers (calibrated, profiles/r01_fetch_calibration.md: ratio 0.975-1.036; "
+                  "the guide's x2 applies to wide coalesced streams only); WRITE_SIZE x 1024 = bytes",
+    "traffic_bytes_per_launch": int(d["fetch_bytes"] + d["write_bytes"]), "l2_hit_rate": d["l2_hit_rate"],
+    "kernel_ms": sum(pmc["main_launch_ms"]) / len(pmc["main_launch_ms"]),
+}
+json.dump(traffic, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
+print(json.dumps({"value": bench["value"], "ms_per_step": bench["ms_per_step"], "roofline": bench["roofline"]["achieved"], "traffic": traffic["traffic_bytes_per_launch"]}))
