@@ -475,7 +475,13 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
     }
 }
 
-__device__ __forceinline__ int popc64(unsigned long long m) { return (int)__builtin_popcountll(m); }
+// 32-bit result in an SGPR: with __builtin_popcountll the compiler keeps wave-uniform counts as 64-bit values and compares them on the VALU
+__device__ __forceinline__ int popc64(unsigned long long m)
+{
+    int r;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
 // number of set bits of m below this lane
 __device__ __forceinline__ int rank_in(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
@@ -908,10 +914,26 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
                 // visiting order (tie-break on triangle id), so this only changes which lanes are busy, not the result.
                 if (popc64(m_node) >= popc64(m_leaf)) {
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
-                    if (cur >= 0) {
+                    // stack levels >= PT_LDS_STACK live in HBM; 0.006 % of the pushes on C4 go there, so the common instance of the
+                    // step (chosen by one wave-uniform branch) does not carry that code at all
+                    if (__ballot(sp >= PT_LDS_STACK) == 0ull) {
+                        if (cur >= 0) {
+                            if (COUNT) ++cn.nodes;
+                            node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                            if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
+                                pend = cur;
+                                if (sp > 0) {
+                                    --sp;
+                                    cur = (int)stack_pop<PT_WAVE, 0x7fffffff>(stack, ovf, sp);
+                                } else {
+                                    cur = PT_DONE;
+                                }
+                            }
+                        }
+                    } else if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
                         node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
-                        if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
+                        if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;
                             if (sp > 0) {
                                 --sp;
