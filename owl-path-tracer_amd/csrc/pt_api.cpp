@@ -18,7 +18,8 @@ extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelPa
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
 extern "C" size_t pt_sort_scratch_bytes(uint32_t n);
-extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch, hipStream_t stream);
+extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0,
+                                            uint32_t* scratch, uint8_t* bucket, hipStream_t stream);
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu);
 extern "C" int pt_debug_block(void);
@@ -60,7 +61,7 @@ struct pt_ctx {
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch;
+    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -70,11 +71,12 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 50;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 75, latency = 0, cost_radius = 2;
 
     pt_stats stats{};
     int last_launches = 0;
     bool last_sorted = false;
+    int last_w = 0, last_h = 0;
     size_t lap_ticks_ofs = 0;
     int last_chunks = 0;
 };
@@ -278,7 +280,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -299,6 +301,8 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
     else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? 1 : (value > 100 ? 100 : value));
+    else if (k == "cost_radius") c->cost_radius = (int)(value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (k == "latency") c->latency = (int)value;
     else if (k == "census_mode") c->census_mode = (int)value;
     else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
     else if (k == "prepass_spp") c->prepass_spp = (int)(value < 1 ? 1 : (value > 15 ? 15 : value));
@@ -506,7 +510,9 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             const int rest = max_samples - c->prepass_spp;
             const int big = std::max(1, (int)((int64_t)rest * c->sticky_pct / 100));
             main_sc = make_schedule(rest, big, rest - big);
-            if ((rc = ensure(c, c->d_cost, (size_t)c->n_pixels))) return rc;
+            if ((rc = ensure(c, c->d_cost, (size_t)W * H))) return rc; // cost image; zero where this rank owns nothing
+            if ((rc = ensure(c, c->d_bucket, (size_t)c->n_pixels))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->d_cost.p, 0, (size_t)W * H, stream));
             if ((rc = ensure(c, c->d_sorted, (size_t)c->n_pixels * 4))) return rc;
             if ((rc = ensure(c, c->d_sort_scratch, pt_sort_scratch_bytes(c->n_pixels)))) return rc;
         } else {
@@ -561,6 +567,12 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs);
     c->last_chunks = n_chunks;
     P.cost_out = nullptr;
+    P.dbg_start = nullptr;
+    P.dbg_cost = nullptr;
+    if (c->latency && sorted) {
+        if ((rc = ensure(c, c->d_dbg_start, (size_t)W * H * 4))) return rc;
+        P.dbg_cost = (uint8_t*)c->d_cost.p;
+    }
     P.census_mode = c->census_mode;
     P.chunk_spp = main_sc.chunk;
     P.n_chunks = n_chunks;
@@ -572,7 +584,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 104; // largest count that still gives 16 waves/CU; 64..255 swept on C4 (profiles/r01_summary.md)
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
     HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
         // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
@@ -604,6 +616,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             P.sample_count = l == 0 ? c->prepass_spp : max_samples - c->prepass_spp;
             P.pixel_ids = l == 0 ? (const uint32_t*)c->d_pixels.p : (const uint32_t*)c->d_sorted.p;
             P.cost_out = l == 0 ? (uint8_t*)c->d_cost.p : nullptr;
+            P.dbg_start = (l == 1 && c->latency) ? (uint32_t*)c->d_dbg_start.p : nullptr;
             P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs) + (l == 0 ? 3 * (n_chunks + 1) + 128 : 0);
             P.ring_tail = (uint32_t*)c->d_laps.p + 64 + (l == 0 ? n_chunks : 0); // the pre-pass only uses its [1]: the spare counter
             if (l == 0) { // one chunk per pixel
@@ -618,8 +631,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
             }
             if (l == 1) {
-                HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p, c->n_pixels,
-                                                 (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, stream));
+                HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, W, H, c->cost_radius, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p,
+                                                 c->n_pixels, (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, (uint8_t*)c->d_bucket.p, stream));
                 HIP_TRY(c, hipEventRecord(c->evm, stream));
             }
         }
@@ -631,6 +644,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     c->ev_pending = true;
     c->last_launches = n_launch;
     c->last_sorted = sorted;
+    c->last_w = W;
+    c->last_h = H;
     c->stats.vgprs = vg;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
@@ -747,7 +762,13 @@ int64_t pt_debug_read_queue(pt_ctx* c, uint32_t* queue_ids, uint32_t* input_ids,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (queue_ids) HIP_TRY(c, hipMemcpy(queue_ids, c->d_sorted.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (input_ids) HIP_TRY(c, hipMemcpy(input_ids, c->d_pixels.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (cost) HIP_TRY(c, hipMemcpy(cost, c->d_cost.p, (size_t)n, hipMemcpyDeviceToHost));
+    if (cost) { // cost image -> cost of each input queue entry
+        std::vector<uint8_t> img((size_t)c->last_w * (size_t)c->last_h);
+        std::vector<uint32_t> ids((size_t)n);
+        HIP_TRY(c, hipMemcpy(img.data(), c->d_cost.p, img.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(ids.data(), c->d_pixels.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) cost[i] = ids[(size_t)i] < img.size() ? img[ids[(size_t)i]] : 0;
+    }
     return n;
 }
 

@@ -392,6 +392,7 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
     const uint32_t pid = gp(P.pixel_ids)[k];
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
+    if (c == 0 && P.dbg_start) gp(P.dbg_start)[pid] = (uint32_t)wall_clock64();
     if (c == 0 && P.sample_begin == 0) {
         rng = rng_init((uint32_t)px, (uint32_t)py); // device.cu:226
         color = vs(0.0f);
@@ -412,6 +413,13 @@ __device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
 __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k, uint32_t c, int px, int py, uint32_t rng, v3 color)
 {
     const bool last_chunk = (int)c + 1 >= P.n_chunks;
+    if (c == 0 && P.dbg_start) { // diagnostics (tools/ab_bench.py latency=1): first-chunk duration by cost class of the pixel
+        const uint32_t pid0 = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
+        const uint32_t dt = (uint32_t)wall_clock64() - gp(P.dbg_start)[pid0];
+        const uint32_t cls = gp(P.dbg_cost)[pid0] >> 2 < 31u ? gp(P.dbg_cost)[pid0] >> 2 : 31u;
+        atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + cls, (unsigned long long)dt);
+        atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + 32 + cls, 1ull);
+    }
     if (last_chunk) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
         if (take_agent(P.ring_tail + P.n_chunks) == P.n_pixels - 1u) {
             gp(P.lap_ticks)[P.n_chunks] = wall_clock64();
@@ -679,7 +687,10 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 ++s;
                 need_gen = true;
                 if (s == chunk_len(P, chunk)) {
-                    if (P.cost_out) { gp(P.cost_out)[qk] = (uint8_t)cost; cost = 0u; }
+                    if (P.cost_out) { // cost image, indexed by pixel id
+                        gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = (uint8_t)cost;
+                        cost = 0u;
+                    }
                     finish_chunk(P, qk, chunk, px, py, ps.rng, color);
                     have_pixel = false;
                     ticket = PT_FRESH;
@@ -782,6 +793,7 @@ __global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kerne
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 
     // every slot starts "fresh" (needs a pixel) and sits in the miss queue so that the first shading passes start them
+    if (blockIdx.x == 0 && lane == 0) gp(P.lap_ticks)[0] = wall_clock64(); // diagnostics timeline origin
     for (int i = lane; i < ns; i += PT_WAVE) {
         w.missq[i] = (uint8_t)i;
         lstate[S_PIX * ns + i] = PT_FRESH;
@@ -1077,6 +1089,26 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
 #define PT_SORT_ITEMS 16
 #define PT_SORT_BUCKETS 16
 
+// Cost of a pixel for the ordering: the maximum over its (2R+1)^2 neighbourhood of the rays the pre-pass counted.  Eight samples
+// are a noisy estimate, but expensive regions are spatially coherent; a truly expensive pixel that looked cheap would start
+// late and finish long after everything else (pixels of other ranks and outside the image count as 0).
+__device__ __forceinline__ uint32_t pixel_cost(const uint8_t* __restrict__ img, uint32_t pid, int W, int H, int R)
+{
+    const int x = (int)(pid % (uint32_t)W), y = (int)(pid / (uint32_t)W);
+    uint32_t m = 0;
+    for (int dy = -R; dy <= R; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -R; dx <= R; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const uint32_t v = img[(size_t)yy * W + xx];
+            m = v > m ? v : m;
+        }
+    }
+    return m;
+}
+
 __device__ __forceinline__ int cost_bucket(uint32_t cost, uint32_t c0)
 {
     const uint32_t extra = cost > c0 ? cost - c0 : 0u; // every sample traces at least its camera ray
@@ -1084,13 +1116,18 @@ __device__ __forceinline__ int cost_bucket(uint32_t cost, uint32_t c0)
     return PT_SORT_BUCKETS - 1 - (int)(b < (uint32_t)(PT_SORT_BUCKETS - 1) ? b : (uint32_t)(PT_SORT_BUCKETS - 1)); // 0 = most expensive
 }
 
-__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8_t* __restrict__ cost, uint32_t n, uint32_t c0, uint32_t* __restrict__ block_hist)
+__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8_t* __restrict__ img, const uint32_t* __restrict__ in, int W, int H, int R, uint32_t n,
+                                                                    uint32_t c0, uint32_t* __restrict__ block_hist, uint8_t* __restrict__ bucket)
 {
     __shared__ uint32_t h[PT_SORT_BUCKETS];
     if (threadIdx.x < PT_SORT_BUCKETS) h[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t first = (blockIdx.x * PT_SORT_BLOCK + threadIdx.x) * PT_SORT_ITEMS;
-    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) atomicAdd(&h[cost_bucket(cost[i], c0)], 1u);
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) {
+        const int b = cost_bucket(pixel_cost(img, in[i], W, H, R), c0);
+        bucket[i] = (uint8_t)b; // per queue entry, for the scatter pass
+        atomicAdd(&h[b], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < PT_SORT_BUCKETS) block_hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
@@ -1114,21 +1151,21 @@ __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scan_kernel(uint32_t* _
     for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = block_hist[i]; block_hist[i] = run; run += v; }
 }
 
-__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scatter_kernel(const uint8_t* __restrict__ cost, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                                       uint32_t n, uint32_t c0, const uint32_t* __restrict__ block_off)
+__global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scatter_kernel(const uint8_t* __restrict__ bucket, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                       uint32_t n, const uint32_t* __restrict__ block_off)
 {
     __shared__ uint32_t cnt[PT_SORT_BUCKETS][PT_SORT_BLOCK];
     const uint32_t t = threadIdx.x;
     for (int b = 0; b < PT_SORT_BUCKETS; ++b) cnt[b][t] = 0u;
     const uint32_t first = (blockIdx.x * PT_SORT_BLOCK + t) * PT_SORT_ITEMS;
-    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) cnt[cost_bucket(cost[i], c0)][t] += 1u;
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) cnt[bucket[i]][t] += 1u;
     __syncthreads();
     if (t < PT_SORT_BUCKETS) { // queue position of (bucket t, thread j) of this block
         uint32_t run = block_off[t * gridDim.x + blockIdx.x];
         for (int j = 0; j < PT_SORT_BLOCK; ++j) { const uint32_t v = cnt[t][j]; cnt[t][j] = run; run += v; }
     }
     __syncthreads();
-    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) out[cnt[cost_bucket(cost[i], c0)][t]++] = in[i];
+    for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) out[cnt[bucket[i]][t]++] = in[i];
 }
 
 extern "C" size_t pt_sort_scratch_bytes(uint32_t n)
@@ -1137,14 +1174,15 @@ extern "C" size_t pt_sort_scratch_bytes(uint32_t n)
     return (size_t)((n + per_block - 1) / per_block) * PT_SORT_BUCKETS * sizeof(uint32_t);
 }
 
-extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch, hipStream_t stream)
+extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0,
+                                            uint32_t* scratch, uint8_t* bucket, hipStream_t stream)
 {
     const uint32_t per_block = PT_SORT_BLOCK * PT_SORT_ITEMS;
     const uint32_t nb = (n + per_block - 1) / per_block;
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(pt_sort_hist_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, cost, n, c0, scratch);
+    hipLaunchKernelGGL(pt_sort_hist_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, cost_img, in, W, H, radius, n, c0, scratch, bucket);
     hipLaunchKernelGGL(pt_sort_scan_kernel, dim3(1), dim3(PT_SORT_BLOCK), 0, stream, scratch, nb * PT_SORT_BUCKETS);
-    hipLaunchKernelGGL(pt_sort_scatter_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, cost, in, out, n, c0, (const uint32_t*)scratch);
+    hipLaunchKernelGGL(pt_sort_scatter_kernel, dim3(nb), dim3(PT_SORT_BLOCK), 0, stream, (const uint8_t*)bucket, in, out, n, (const uint32_t*)scratch);
     return hipGetLastError();
 }
 

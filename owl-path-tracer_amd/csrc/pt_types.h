@@ -68,7 +68,9 @@ struct PtKernelParams {
     uint32_t* ring_tail;       // ring_tail[c] = entries published to ring c so far
     unsigned long long* lap_ticks; // [0] = s_memrealtime (100 MHz) at kernel entry, [c + 1] = when the last pixel finished chunk c (diagnostics)
     uint32_t* error_flag;      // set to 1 by a wave whose scheduler watchdog fired
-    uint8_t* cost_out;         // cost pre-pass only (n_chunks == 1): rays traced per queue entry, saturating at 255
+    uint32_t* dbg_start;       // diagnostics (option "latency"): per pixel, clock at the start of its first chunk; null otherwise
+    uint8_t* dbg_cost;         // diagnostics: per pixel cost of the pre-pass
+    uint8_t* cost_out;         // cost pre-pass only (n_chunks == 1): cost image, rays traced per pixel id (saturating at 255)
     PtTexDesc env_map;
     float cam[12];
     float env_color[3];

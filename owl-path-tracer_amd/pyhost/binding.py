@@ -258,7 +258,8 @@ class Context:
             self._check(int(n), "pt_debug_read_laps")
         m = (int(n) - 128) // 3
         ms = lambda x: round((int(x) - int(t[0])) / 1e5, 2)
-        return {"last_done_ms": [ms(x) for x in t[1:m]], "last_start_ms": [ms(x) for x in t[m + 1:2 * m]], "last_entry": [int(x) for x in t[2 * m + 1:3 * m]]}
+        return {"last_done_ms": [ms(x) for x in t[1:m]], "last_start_ms": [ms(x) for x in t[m + 1:2 * m]], "last_entry": [int(x) for x in t[2 * m + 1:3 * m]],
+                "first_chunk_ticks_by_cost_class": [int(x) for x in t[3 * m:3 * m + 32]], "first_chunk_count_by_cost_class": [int(x) for x in t[3 * m + 32:3 * m + 64]]}
 
     def debug_eval(self, op, inputs, out_stride):
         x = np.ascontiguousarray(inputs, np.float32)

@@ -226,6 +226,35 @@ def test_cornell_image_bitwise_and_golden(gpu, orc, cornell):
     assert st["kernel_ms"] > 0 and st["launches"] == 2  # cost pre-pass + main launch over the cost-ordered pixel queue
 
 
+def test_cost_ordered_queue_properties(gpu, cornell):
+    """The cost pre-pass + counting sort (default schedule from 32 spp): the queue is a permutation of the shard's pixels, ordered
+    by the 5x5 neighbourhood maximum of the pre-pass cost in non-increasing class order, and the costs are >= one ray per sample."""
+    env = B.make_env(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=env)
+    W, H = 96, 80
+    cam = _cam(cornell, W, H)
+    gpu.set_pixel_shard(1, 2, 16)
+    gpu.render(cam, W, H, 40, 16)
+    assert gpu.stats()["launches"] == 2 and gpu.stats()["prepass_ms"] > 0
+    q, ids, cost = gpu.read_queue(W * H)
+    gpu.set_pixel_shard(0, 1, 16)
+    own = B.shard_pixels(W, H, 16, 1, 2)
+    np.testing.assert_array_equal(ids, own)
+    np.testing.assert_array_equal(np.sort(q), np.sort(own))
+    assert cost.min() >= 8 and cost.max() > 16  # 8 pre-pass samples, at least the camera ray each; the box interior bounces
+    img = np.zeros((H, W), np.int32)
+    img.reshape(-1)[ids] = cost
+    pad = np.pad(img, 2)
+    nmax = np.max([pad[dy:dy + H, dx:dx + W] for dy in range(5) for dx in range(5)], axis=0).reshape(-1)
+    cls = np.minimum(15, np.maximum(0, nmax[q] - 8) * 3 // 8)  # cost_bucket() of pt_kernel.hip, before the descending flip
+    assert np.all(np.diff(cls) <= 0), "queue classes must be non-increasing (most expensive first)"
+    # stable within a class: input order is kept
+    pos = np.empty(W * H, np.int64)
+    pos[ids] = np.arange(ids.size)
+    for c in np.unique(cls):
+        assert np.all(np.diff(pos[q[cls == c]]) > 0)
+
+
 def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
     """All four lobes + sheen + textures + emitter in one small scene (the car.json material set on spheres)."""
     _, car = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "car.json"))
