@@ -372,6 +372,14 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_depth = (uint64_t)c->bvh.depth;
     c->stats.n_triangles = n_tris;
     if (c->bvh.depth > PT_MAX_STACK) return fail(c, PT_E_LIMIT, "BVH depth %d exceeds %d", c->bvh.depth, PT_MAX_STACK);
+    { // shading records follow the triangles into leaf order; the triangle record carries the material index as well
+        std::vector<PtShade> by_leaf(n_tris);
+        for (size_t i = 0; i < n_tris; ++i) {
+            by_leaf[i] = c->shade[(size_t)c->bvh.tris[i].id];
+            c->bvh.tris[i].material = by_leaf[i].material;
+        }
+        c->shade.swap(by_leaf);
+    }
 
     // ---- textures, materials, environment ----
     c->textures.assign((size_t)n_textures, HostTexture{});

@@ -189,7 +189,8 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
         PtTri& t = out->tris[i];
         std::memcpy(t.p0, positions + (size_t)id * 9, 36);
         t.id = id;
-        t.pad[0] = t.pad[1] = 0;
+        t.material = -1; // filled in by the caller that owns the shading records (pt_api.cpp)
+        t.pad = 0;
     }
 }
 

@@ -231,11 +231,12 @@ __device__ __forceinline__ int shade_hit(const PtKernelParams& P, const float* m
         return SR_END;
     }
     const size_t tb = (size_t)(uint32_t)tslot * sizeof(PtTri);
+    // triangle and shading record share the leaf-order index, and the triangle record repeats the material index: two dependent
+    // round trips (records, then material) instead of three
     const f32x4 a = ldg4(P.tris, tb), b = ldg4(P.tris, tb + 16), c = ldg4(P.tris, tb + 32);
-    const int tid = __float_as_int(c.y);
-    const size_t sb = (size_t)(uint32_t)tid * sizeof(PtShade);
+    const size_t sb = (size_t)(uint32_t)tslot * sizeof(PtShade);
     const f32x4 s0 = ldg4(P.shade, sb), s1 = ldg4(P.shade, sb + 16), s2 = ldg4(P.shade, sb + 32), s3 = ldg4(P.shade, sb + 48);
-    int mi = __float_as_int(s2.y);
+    int mi = __float_as_int(c.z);
     Material mat = material_default(); // device.cu:150-154
     int tex_slot = -1;
     if (mi >= 0) {

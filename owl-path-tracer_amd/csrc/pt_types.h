@@ -20,11 +20,12 @@ static_assert(sizeof(PtNode) == 64, "PtNode must be 64 bytes");
 struct PtTri {
     float p0[3], p1[3], p2[3];
     int32_t id;
-    uint32_t pad[2];
+    int32_t material; // copy of the shading record's material index: the material fetch need not wait for that record
+    uint32_t pad;
 };
 static_assert(sizeof(PtTri) == 48, "PtTri must be 48 bytes");
 
-// Shading record per GLOBAL triangle id: the three vertex normals (device.cu:63-73), the material index
+// Shading record per triangle, in LEAF order like PtTri (one index serves both): the three vertex normals (device.cu:63-73), the material index
 // (entity_data.material_index) and the three texcoords (device.cu:75-94).  64 bytes = 4 x dwordx4.
 // Flattened per triangle instead of the reference's buffer-of-buffers double indirection.
 struct PtShade {
