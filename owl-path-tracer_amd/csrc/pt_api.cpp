@@ -71,7 +71,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 75, latency = 0, cost_radius = 2;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 75, latency = 0, cost_radius = 2, timeline = 0;
 
     pt_stats stats{};
     int last_launches = 0;
@@ -302,6 +302,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
     else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? 1 : (value > 100 ? 100 : value));
     else if (k == "cost_radius") c->cost_radius = (int)(value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (k == "timeline") c->timeline = value != 0;
     else if (k == "latency") c->latency = (int)value;
     else if (k == "census_mode") c->census_mode = (int)value;
     else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
@@ -575,6 +576,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs);
     c->last_chunks = n_chunks;
     P.cost_out = nullptr;
+    P.timeline = c->timeline;
     P.dbg_start = nullptr;
     P.dbg_cost = nullptr;
     if (c->latency && sorted) {

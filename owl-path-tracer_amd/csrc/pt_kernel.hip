@@ -377,20 +377,19 @@ __device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P)
 }
 
 // Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
-__device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& k, uint32_t& c, int& px, int& py, uint32_t& rng,
-                                            v3& color)
+__device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& c, int& px, int& py, uint32_t& rng, v3& color)
 {
+    uint32_t pid;
     if (ticket < P.n_pixels) {
-        k = ticket;
+        pid = gp(P.pixel_ids)[ticket];
         c = 0;
     } else {
-        const uint32_t e = ld_agent(P.ring + ticket); // ring c = ticket / n_pixels, entry ticket % n_pixels
+        const uint32_t e = ld_agent(P.ring + ticket); // ring c = ticket / n_pixels, entry ticket % n_pixels; cell = pixel id + 1
         if (e == 0u) return false;                    // chunk c - 1 of that pixel is still running somewhere
-        k = e - 1u;
+        pid = e - 1u;
         c = ticket / P.n_pixels;
     }
-    if (ticket % P.n_pixels == P.n_pixels - 1u) gp(P.lap_ticks)[(P.n_chunks + 1) + 1 + c] = wall_clock64(); // last start of chunk c
-    const uint32_t pid = gp(P.pixel_ids)[k];
+    if (P.timeline && ticket % P.n_pixels == P.n_pixels - 1u) gp(P.lap_ticks)[(P.n_chunks + 1) + 1 + c] = wall_clock64(); // last start of chunk c
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
     if (c == 0 && P.dbg_start) gp(P.dbg_start)[pid] = (uint32_t)wall_clock64();
@@ -410,21 +409,21 @@ __device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
     return (int)c < P.n_full ? P.chunk_spp : P.tail_len[(int)c - P.n_full];
 }
 
-// The slot finished chunk c of queue entry k: write the framebuffer (device.cu:246-253) or hand the pixel on.
-__device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k, uint32_t c, int px, int py, uint32_t rng, v3 color)
+// The slot finished chunk c of its pixel: write the framebuffer (device.cu:246-253) or hand the pixel on.
+__device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c, int px, int py, uint32_t rng, v3 color)
 {
     const bool last_chunk = (int)c + 1 >= P.n_chunks;
+    const uint32_t pid = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
     if (c == 0 && P.dbg_start) { // diagnostics (tools/ab_bench.py latency=1): first-chunk duration by cost class of the pixel
-        const uint32_t pid0 = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
-        const uint32_t dt = (uint32_t)wall_clock64() - gp(P.dbg_start)[pid0];
-        const uint32_t cls = gp(P.dbg_cost)[pid0] >> 2 < 31u ? gp(P.dbg_cost)[pid0] >> 2 : 31u;
+        const uint32_t dt = (uint32_t)wall_clock64() - gp(P.dbg_start)[pid];
+        const uint32_t cls = gp(P.dbg_cost)[pid] >> 2 < 31u ? gp(P.dbg_cost)[pid] >> 2 : 31u;
         atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + cls, (unsigned long long)dt);
         atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + 32 + cls, 1ull);
     }
-    if (last_chunk) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
+    if (last_chunk && P.timeline) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
         if (take_agent(P.ring_tail + P.n_chunks) == P.n_pixels - 1u) {
             gp(P.lap_ticks)[P.n_chunks] = wall_clock64();
-            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + P.n_chunks] = k;
+            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + P.n_chunks] = pid;
         }
     }
     if (last_chunk && P.sample_begin + P.sample_count >= P.max_samples) {
@@ -436,19 +435,20 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t k
         orgb[3 * ofs + 2] = out.z;
         if (P.out_rgba8) gp(P.out_rgba8)[ofs] = make_rgba(out);
     } else {
-        const uint32_t pid = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
         st_agent(P.rng_state + pid, rng);
         uint32_t* a = reinterpret_cast<uint32_t*>(P.accum) + 3 * (size_t)pid;
         st_agent(a, __float_as_uint(color.x));
         st_agent(a + 1, __float_as_uint(color.y));
         st_agent(a + 2, __float_as_uint(color.z));
         if (last_chunk) return; // the next launch resumes the pixel (cost pre-pass -> main pass)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state has left this CU before the ring entry does
+        // the ring position is taken while the state stores are still in flight (one round trip for both); the entry itself
+        // leaves only after the state has left this CU
         const uint32_t pos = take_agent(P.ring_tail + (c + 1)); // completion order of chunk c = start order of chunk c + 1
-        st_agent(P.ring + (size_t)(c + 1) * P.n_pixels + pos, k + 1u);
-        if (pos == P.n_pixels - 1u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(P.ring + (size_t)(c + 1) * P.n_pixels + pos, pid + 1u);
+        if (P.timeline && pos == P.n_pixels - 1u) {
             gp(P.lap_ticks)[c + 1] = wall_clock64();
-            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + c + 1] = k;
+            gp(P.lap_ticks)[2 * (P.n_chunks + 1) + c + 1] = pid;
         }
     }
 }
@@ -655,8 +655,8 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         const bool running = pid != PT_FRESH;
         uint32_t ticket = running ? PT_FRESH : GF(S_RNG, ps_slot);
         const uint32_t qkc = running ? GF(S_QKC, ps_slot) : 0u;
-        // top byte of S_QKC: chunk index, or in the cost pre-pass (one chunk per pixel) the rays traced so far
-        uint32_t qk = qkc & 0xffffffu, chunk = P.cost_out ? 0u : qkc >> 24, cost = P.cost_out ? qkc >> 24 : 0u;
+        // S_QKC: chunk index, or in the cost pre-pass (one chunk per pixel) the rays traced so far
+        uint32_t chunk = P.cost_out ? 0u : qkc, cost = P.cost_out ? qkc : 0u;
         uint32_t pack = running ? GF(S_PACK, ps_slot) : 0u;
         int s = (int)(pack & 0xffffu);
         PathState ps;
@@ -692,9 +692,9 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                         gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = (uint8_t)cost;
                         cost = 0u;
                     }
-                    finish_chunk(P, qk, chunk, px, py, ps.rng, color);
+                    ticket = take_ticket(P); // in flight while finish_chunk stores the pixel's state
+                    finish_chunk(P, chunk, px, py, ps.rng, color);
                     have_pixel = false;
-                    ticket = PT_FRESH;
                 }
             } else {
                 to_ray = true;
@@ -705,7 +705,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 if (ticket == PT_FRESH) ticket = take_ticket(P);
                 if (ticket == PT_NO_TICKET) {
                     died = true;
-                } else if (start_chunk(P, ticket, qk, chunk, px, py, ps.rng, color)) {
+                } else if (start_chunk(P, ticket, chunk, px, py, ps.rng, color)) {
                     have_pixel = true;
                     s = 0;
                 } else {
@@ -723,7 +723,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 GF(S_RNG, ps_slot) = ticket;
             } else {
                 GF(S_PIX, ps_slot) = (uint32_t)px | ((uint32_t)py << 16);
-                GF(S_QKC, ps_slot) = qk | ((P.cost_out ? cost : chunk) << 24);
+                GF(S_QKC, ps_slot) = P.cost_out ? cost : chunk;
                 GF(S_RNG, ps_slot) = ps.rng;
                 GF(S_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
                 GF(S_COLX, ps_slot) = __float_as_uint(color.x);

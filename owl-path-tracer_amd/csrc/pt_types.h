@@ -65,7 +65,7 @@ struct PtKernelParams {
     uint32_t* out_rgba8;       // optional
     PtCounters* counters;      // optional (instrumented build)
     uint32_t* slot_state;      // wavefront kernel: per-wave path-slot state + park area (pt_wave_state_words each)
-    uint32_t* ring;            // wavefront kernel: ring[c * n_pixels + i] = 1 + queue entry whose chunk c may start (0: not yet), in completion order of chunk c - 1
+    uint32_t* ring;            // wavefront kernel: ring[c * n_pixels + i] = 1 + id of the pixel whose chunk c may start (0: not yet), in completion order of chunk c - 1
     uint32_t* ring_tail;       // ring_tail[c] = entries published to ring c so far
     unsigned long long* lap_ticks; // [0] = s_memrealtime (100 MHz) at kernel entry, [c + 1] = when the last pixel finished chunk c (diagnostics)
     uint32_t* error_flag;      // set to 1 by a wave whose scheduler watchdog fired
@@ -89,6 +89,7 @@ struct PtKernelParams {
     int32_t ns;                // wavefront kernel: path slots per wave (64..255)
     int32_t chunk_spp, n_chunks; // wavefront kernel: samples per (pixel, chunk) ticket and chunks per pixel
     uint32_t n_tickets;        // n_pixels * n_chunks
+    int32_t timeline;          // diagnostics: record the chunk timeline (pt_debug_read_laps); costs one more atomic per finished pixel
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];

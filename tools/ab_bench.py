@@ -64,7 +64,8 @@ def main():
         cen["winddown_time_share"] = round(cen["winddown_ticks"] / max(1, cyc["total"]), 4)
         cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
         print(json.dumps(cen))
-    print(json.dumps({"laps_ms": ctx.read_laps()}))
+    if opts.get("timeline"):
+        print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
                       "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
                       "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"]}))
