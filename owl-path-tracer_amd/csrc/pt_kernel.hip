@@ -763,8 +763,11 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 }
 } // namespace
 
+// The instrumented instance gets 256 VGPRs (2 waves/SIMD): with 128 it spills ~50 registers to scratch, and a spilling build of this
+// kernel rendered wrong pixels in round 1 (both instrumented instances, identical source otherwise; never the 128-VGPR product
+// instance, which does not spill).  pt_render refuses to launch any instance that needs scratch (pt_kernel_geometry).
 template <bool COUNT>
-__global__ void __launch_bounds__(PT_WAVE, PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
+__global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
 {
     // The parameter block lives in HBM and is read with scalar loads where it is used.  Passed by value it arrives as
     // s_load_dwordx16 tuples that stay live for the whole kernel; the register allocator then spilled them to VGPR lanes
@@ -1232,6 +1235,7 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, fn);
     if (e != hipSuccess) return e;
+    if (variant != 1 && fa.localSizeBytes != 0) return hipErrorInvalidConfiguration; // register spills: see pt_render_wave_kernel
     *vgprs = fa.numRegs;
     int nb = 0;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, *block, *lds_bytes);
