@@ -5,16 +5,17 @@
 // Two schedulers over the same device functions (DESIGN.md "kernel"):
 //
 //  pt_render_wave_kernel (default, "wavefront-scheduled"): one wave64 per workgroup owns ns path slots
-//    (a slot = one pixel in flight with its RNG stream, accumulators and current ray) plus two slot queues:
-//    rays waiting for traversal and hits waiting for shading.  The wave alternates between
-//      * a TRAVERSAL phase: every lane walks one ray; each step the wave executes either one BVH-node step or one
-//        triangle test, whichever more lanes are waiting for (ballot majority); finished lanes retire their hit into
-//        the hit queue and immediately pull the next ray, so the traversal loop runs with ~64 busy lanes;
-//      * a SHADING phase over 64 queued hits at a time (miss / emitter / BSDF sample / Russian roulette / next
-//        camera ray / next pixel), which emits the continuation rays back into the ray queue.
+//    (a slot = one pixel in flight with its RNG stream, accumulators and current ray) plus three slot queues:
+//    rays waiting for traversal, hits and misses waiting for shading.  The wave alternates between
+//      * a TRAVERSAL phase: every lane walks one ray (speculatively: one stashed leaf per lane); each step the wave
+//        executes either one BVH-node step or one whole-leaf triangle step, whichever more lanes are waiting for
+//        (ballot majority); finished lanes retire in batches into the hit / miss queue and pull the next ray;
+//      * a SHADING pass over up to 64 queued hits (emitter / BSDF sample / Russian roulette) or misses (environment,
+//        sample accumulation, next camera ray / next work item), which emits the continuation rays into the ray queue.
 //    Lanes are workers, not pixel owners: a ray's lane is unrelated to the lane that shades its hit.  The per-pixel
 //    sample order -- hence the reference's per-pixel RNG stream (device.cu:226-243) -- is preserved because a slot
-//    has at most one ray in flight.
+//    has at most one ray in flight.  Work items are (pixel, sample chunk) tickets; the host orders the pixel queue by a
+//    cost pre-pass (pt_api.cpp, "schedule").
 //
 //  pt_render_kernel (option kernel=1): the simple persistent lane-per-pixel form kept for A/B measurements.
 //
@@ -29,9 +30,6 @@ using namespace ptd;
 #define PT_WAVE 64
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 4
-#endif
-#ifndef PT_NS_DEFAULT
-#define PT_NS_DEFAULT 192  // path slots per wave: >= 64 + 2*63 + 1 so that an empty ray queue implies a full hit or miss batch
 #endif
 #ifndef PT_WATCHDOG_ROUNDS
 #define PT_WATCHDOG_ROUNDS 20000000 // wave-loop rounds (shading passes + traversal phases) before a wave gives up; a C5 frame needs ~2e5 per wave
@@ -577,7 +575,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(const PtKernelParam
 #define PT_LDS_STACK 12
 #endif
 enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
-// S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = queue entry | chunk << 24
+// S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = chunk index (cost pre-pass: rays traced so far)
 enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
 // S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
