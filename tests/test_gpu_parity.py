@@ -318,6 +318,20 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     gpu.set_option("schedule", 1)
     assert_bitwise(ring, by_cost, "FIFO ring == cost-ordered queue")
     assert_bitwise(ring_fixed, by_cost, "fixed chunks == cost-ordered queue")
+    # schedule corner cases against the oracle: smallest spp that sorts (4 x prepass_spp), odd counts, a first chunk of 1 % / 100 %
+    # of the samples, no halving tail, a 1-sample pre-pass, no neighbourhood smoothing, few slots per wave
+    S = orc.Scene(cornell["flat"])
+    oenv = orc.make_env(color=(1, 1, 1), intensity=0.0)
+    for spp, opts in ((32, {}), (33, {"sticky_pct": 1}), (41, {"sticky_pct": 100}), (37, {"chunk_tail_min": 0, "sticky_pct": 50}),
+                      (36, {"prepass_spp": 1, "cost_radius": 0}), (45, {"prepass_spp": 11, "chunk_tail_min": 3, "slots_per_wave": 64})):
+        for k, v in opts.items():
+            gpu.set_option(k, v)
+        got, _ = gpu.render(cam, W, H, spp, 16)
+        assert gpu.stats()["launches"] == 2, (spp, opts)
+        for k, v in {"sticky_pct": 75, "chunk_tail_min": 16, "prepass_spp": 8, "cost_radius": 2, "slots_per_wave": 0}.items():
+            gpu.set_option(k, v)
+        want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, spp, 16)
+        assert_bitwise(got, want, "schedule %r at %d spp" % (opts, spp))
     # pixel-tile shards are disjoint: the sum over ranks (what the RCCL reduce computes) is the 1-GPU image bit-for-bit
     acc = np.zeros_like(full)
     for r in range(3):
