@@ -40,6 +40,15 @@ using namespace ptd;
 #ifndef PT_MIN_BATCH
 #define PT_MIN_BATCH 32    // smallest shading batch taken early
 #endif
+#ifndef PT_NODE_KEEP
+#define PT_NODE_KEEP 24  // > 0: keep doing bursts of node steps (up to PT_NODE_BURSTS) while at least this many lanes want one
+#endif
+#ifndef PT_NODE_BURSTS
+#define PT_NODE_BURSTS 3
+#endif
+#ifndef PT_NODE_REPS
+#define PT_NODE_REPS 2 // consecutive node steps per scheduler iteration in the common (LDS-stack-only) instance
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -930,20 +939,33 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
                     if (COUNT) { cn.sched[0] += 1; cn.sched[1] += popc64(m_node); }
                     // stack levels >= PT_LDS_STACK live in HBM; 0.006 % of the pushes on C4 go there, so the common instance of the
                     // step (chosen by one wave-uniform branch) does not carry that code at all
-                    if (__ballot(sp >= PT_LDS_STACK) == 0ull) {
-                        if (cur >= 0) {
-                            if (COUNT) ++cn.nodes;
-                            node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
-                            if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
-                                pend = cur;
-                                if (sp > 0) {
-                                    --sp;
-                                    cur = (int)stack_pop<PT_WAVE, 0x7fffffff>(stack, ovf, sp);
-                                } else {
-                                    cur = PT_DONE;
+                    // The scheduler round around a step (three ballots, retire test, majority vote, loop-carried copies) costs about as
+                    // much as the step: node steps come in bursts of PT_NODE_REPS, repeated while >= PT_NODE_KEEP lanes still want one
+                    // (1 x 1 -> 2 x up to 3: C4 626 -> 599 ms, its 1/8 shard 480 -> 435 ms, C2 98 -> 91 ms).
+                    if (__ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) == 0ull) {
+#if PT_NODE_KEEP > 0
+                      for (int burst = 0; burst < PT_NODE_BURSTS; ++burst) {
+                        if (burst > 0 && (popc64(__ballot(cur >= 0)) < PT_NODE_KEEP || __ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) != 0ull)) break;
+#endif
+#pragma unroll
+                        for (int rep = 0; rep < PT_NODE_REPS; ++rep) {
+                            if (cur >= 0) {
+                                if (COUNT) ++cn.nodes;
+                                node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                                if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
+                                    pend = cur;
+                                    if (sp > 0) {
+                                        --sp;
+                                        cur = (int)stack_pop<PT_WAVE, 0x7fffffff>(stack, ovf, sp);
+                                    } else {
+                                        cur = PT_DONE;
+                                    }
                                 }
                             }
                         }
+#if PT_NODE_KEEP > 0
+                      }
+#endif
                     } else if (cur >= 0) {
                         if (COUNT) ++cn.nodes;
                         node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
