@@ -132,7 +132,7 @@ int pt_synchronize(pt_ctx* ctx);
  *   "kernel" 2 (default, wavefront-scheduled) | 1 (lane per pixel);  "count" 0/1: instrumented kernel that fills pt_stats;
  *   "leaf_size", "max_bvh_depth": BVH builder, next pt_upload_scene;  "blocks_per_cu", "slots_per_wave": launch geometry;
  *   "schedule" 1 (default: cost pre-pass + cost-ordered queue, from 4 x prepass_spp samples per pixel) | 0 (chunks only);
- *   "prepass_spp" (8), "cost_radius" (2: cost = maximum over the (2r+1)^2 neighbourhood), "sticky_pct" (75: share of the
+ *   "prepass_spp" (8), "cost_radius" (2: cost = maximum over the (2r+1)^2 neighbourhood), "sticky_pct" (automatic, 10-75: share of the
  *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (16: smallest of the
  *   halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
  *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build. */

@@ -71,7 +71,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = 75, latency = 0, cost_radius = 2, timeline = 0;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0;
 
     pt_stats stats{};
     int last_launches = 0;
@@ -300,7 +300,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "blocks_per_cu") c->blocks_per_cu = (int)(value < 0 ? 0 : value);
     else if (k == "leaf_size") c->leaf_size = (int)value;
     else if (k == "max_bvh_depth") c->max_bvh_depth = (int)value;
-    else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? 1 : (value > 100 ? 100 : value));
+    else if (k == "sticky_pct") c->sticky_pct = (int)(value < 1 ? -1 : (value > 100 ? 100 : value)); // < 1: automatic
     else if (k == "cost_radius") c->cost_radius = (int)(value < 0 ? 0 : (value > 8 ? 8 : value));
     else if (k == "timeline") c->timeline = value != 0;
     else if (k == "latency") c->latency = (int)value;
@@ -478,6 +478,34 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
 
     // kernel 1 (lane-per-pixel): optional spp chunks = separate launches.  kernel 2 (wavefront): ONE persistent launch that
     // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
+    PtKernelParams P;
+    fill_params(c, P);
+
+    // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
+    // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
+    size_t lds = 0, state_words = 0;
+    int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
+    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+    if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
+        // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
+        long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
+        if (fit < want_ns) {
+            want_ns = (int)std::max(64L, fit);
+            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+        }
+    }
+    if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
+    int bpc = c->blocks_per_cu > 0 ? std::min(c->blocks_per_cu, occ) : occ;
+    long want = ((long)c->n_pixels + ns - 1) / ns; // never more path slots than pixels: a pixel's chunks are sequential
+    if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
+    int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
+    if (state_words) {
+        if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
+        P.slot_state = (uint32_t*)c->d_slots.p;
+    }
+    P.ns = ns;
+
     // Chunk schedule of one wavefront launch over `total` samples per pixel: n_full chunks of `chunk` samples, then the rest in
     // halving chunks (rem/2, rem/4, ... >= chunk_tail_min).  A frame ends when its slowest in-flight work item ends, so the
     // last items must be short (profiles/r01_summary.md, "wind-down").
@@ -517,7 +545,18 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         n_launch = sorted ? 2 : 1;
         if (sorted) {
             const int rest = max_samples - c->prepass_spp;
-            const int big = std::max(1, (int)((int64_t)rest * c->sticky_pct / 100));
+            // Share of a pixel's remaining samples that its first slot renders in one go.  With many more pixels than slots the
+            // frame is throughput-bound and hand-offs are pure overhead: 75 %.  With all pixels in flight from the start (small
+            // images, one shard of eight) the frame is the longest pixels' sample chains, and every hand-off moves such a chain
+            // out of the wave it shares with its (equally expensive) neighbours into whatever wave has idle slots: 10-25 %.
+            // Measured on C4 (ms; pixels / slots = 0.66, 1.3, 2.6, 5.3): 10 %: 380 430 511 -, 25 %: 387 438 494 650,
+            // 50 %: 408 435 486 633, 75 %: 470 485 504 608.
+            int sticky = c->sticky_pct;
+            if (sticky < 1) {
+                const double ratio = (double)c->n_pixels / ((double)c->num_cus * (double)bpc * (double)ns);
+                sticky = (int)std::min(75.0, std::max(10.0, 20.0 * ratio));
+            }
+            const int big = std::max(1, (int)((int64_t)rest * sticky / 100));
             main_sc = make_schedule(rest, big, rest - big);
             if ((rc = ensure(c, c->d_cost, (size_t)W * H))) return rc; // cost image; zero where this rank owns nothing
             if ((rc = ensure(c, c->d_bucket, (size_t)c->n_pixels))) return rc;
@@ -556,8 +595,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(PtCounters), stream));
     }
 
-    PtKernelParams P;
-    fill_params(c, P);
     std::memcpy(P.cam, cam, sizeof(float) * 12);
     P.pixel_ids = (const uint32_t*)c->d_pixels.p;
     P.n_pixels = c->n_pixels;
@@ -589,31 +626,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
     P.n_full = main_sc.n_full;
     for (int i = 0; i < PT_MAX_TAIL_CHUNKS; ++i) P.tail_len[i] = main_sc.tail_len[i];
-
-    // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
-    // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
-    size_t lds = 0, state_words = 0;
-    int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
-    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
-    if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
-        // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
-        long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
-        if (fit < want_ns) {
-            want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
-        }
-    }
-    if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
-    int bpc = c->blocks_per_cu > 0 ? std::min(c->blocks_per_cu, occ) : occ;
-    long want = ((long)c->n_pixels + ns - 1) / ns; // never more path slots than pixels: a pixel's chunks are sequential
-    if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
-    int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
-    if (state_words) {
-        if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
-        P.slot_state = (uint32_t*)c->d_slots.p;
-    }
-    P.ns = ns;
 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     if (c->kernel == 2 && (rc = ensure(c, c->d_params, sizeof(PtKernelParams) * (size_t)n_launch))) return rc;
