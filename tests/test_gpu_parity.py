@@ -344,6 +344,16 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
         acc += part
     gpu.set_pixel_shard(0, 1, 16)
     assert_bitwise(acc, full, "sum of shards == full")
+    # the same through the cost-ordered schedule (each rank sorts its own shard; the cost image is zero where it owns nothing)
+    full36, _ = gpu.render(cam, W, H, 36, 16)
+    acc = np.zeros_like(full36)
+    for r in range(2):
+        gpu.set_pixel_shard(r, 2, 16)
+        part, _ = gpu.render(cam, W, H, 36, 16)
+        assert gpu.stats()["launches"] == 2
+        acc += part
+    gpu.set_pixel_shard(0, 1, 16)
+    assert_bitwise(acc, full36, "sum of cost-ordered shards == full")
     # material hot-swap without BVH rebuild (reset_field, application.cpp:297-304)
     mats = np.stack(_mats(cornell)).copy()
     mats[1, 7] = 0.9  # sphere roughness
