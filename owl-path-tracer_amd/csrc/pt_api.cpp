@@ -486,7 +486,12 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
     int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
-    HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+    {
+        const hipError_t ge = pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ);
+        if (ge == hipErrorInvalidConfiguration)
+            return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
+        HIP_TRY(c, ge);
+    }
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
         // small images: fewer slots per wave so that at least 8 waves per CU have pixels (never below 64)
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
