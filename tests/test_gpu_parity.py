@@ -200,6 +200,15 @@ def test_cube_image_bitwise_c1(gpu, orc, cube, scene_io):
     for k in ("samples", "rays", "scatters", "env_misses", "nan_retries"):
         assert st[k] == cnt[k], k
     assert rgb.std() > 0.01
+    # short jobs (every slot renders one pixel and dies: all wind-down) through both kernel instances, plain and instrumented: a
+    # register-spilling build of the instrumented instance once rendered hundreds of wrong pixels exactly here
+    for spp, depth in ((1, 2), (1, 3), (2, 2)):
+        want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, spp, depth)
+        for count in (0, 1):
+            gpu.set_option("count", count)
+            got, _ = gpu.render(cam, W, H, spp, depth)
+            gpu.set_option("count", 0)
+            assert_bitwise(got, want, "cube %d spp depth %d count=%d" % (spp, depth, count))
 
 
 def test_cornell_image_bitwise_and_golden(gpu, orc, cornell):
