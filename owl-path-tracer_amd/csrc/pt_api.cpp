@@ -71,7 +71,8 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1;
+    int tune[8] = {};
 
     pt_stats stats{};
     int last_launches = 0;
@@ -226,6 +227,7 @@ void fill_params(pt_ctx* c, PtKernelParams& P)
     P.n_tris = (int)c->bvh.tris.size();
     P.n_materials = c->n_materials;
     P.stack_entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
+    for (int i = 0; i < 8; ++i) P.tune[i] = c->tune[i];
 }
 
 } // namespace
@@ -310,6 +312,10 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "chunk_tail_min") c->chunk_tail_min = (int)(value < 0 ? 0 : (value > 65535 ? 65535 : value));
     else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
     else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
+    else if (k == "adaptive") c->tune[5] = value ? 1 : 2;
+    else if (k == "node_pairs") c->node_pairs = value != 0;
+    else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
+    else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '7') c->tune[k[4] - '0'] = (int)value;
     else if (k == "kernel") {
         if (value != 1 && value != 2) return fail(c, PT_E_INVALID, "kernel must be 1 (lane-per-pixel) or 2 (wavefront-scheduled)");
         c->kernel = (int)value;
@@ -373,10 +379,15 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_depth = (uint64_t)c->bvh.depth;
     c->stats.n_triangles = n_tris;
     if (c->bvh.depth > PT_MAX_STACK) return fail(c, PT_E_LIMIT, "BVH depth %d exceeds %d", c->bvh.depth, PT_MAX_STACK);
-    { // shading records follow the triangles into leaf order; the triangle record carries the material index as well
-        std::vector<PtShade> by_leaf(n_tris);
-        for (size_t i = 0; i < n_tris; ++i) {
-            by_leaf[i] = c->shade[(size_t)c->bvh.tris[i].id];
+    pt_bvh_layout(&c->bvh, c->node_pairs, c->leaf_align);
+    c->stats.bvh_nodes = c->bvh.nodes.size();
+    { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
+        const size_t n_slots = c->bvh.tris.size();
+        std::vector<PtShade> by_leaf(n_slots);
+        for (size_t i = 0; i < n_slots; ++i) {
+            const int32_t id = c->bvh.tris[i].id;
+            if (id == 0x7fffffff) { std::memset(&by_leaf[i], 0, sizeof(PtShade)); by_leaf[i].material = -1; continue; }
+            by_leaf[i] = c->shade[(size_t)id];
             c->bvh.tris[i].material = by_leaf[i].material;
         }
         c->shade.swap(by_leaf);

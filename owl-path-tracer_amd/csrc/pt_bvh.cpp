@@ -141,6 +141,86 @@ struct Builder {
 
 } // namespace
 
+// ---- memory layout passes (the tree itself is untouched: same boxes, same topology, same leaf contents) -----------------------
+// L2 misses are served at one 128-byte line per request whatever part of the line is used (measured: tools/gather_rec.hip,
+// profiles/r02_gather_ceilings.md), so records that are read together should share lines.
+
+// Sibling pairs: the two children of a node that are internal nodes get adjacent records, the pair aligned to 128 bytes
+// (index 2k, 2k + 1); a pair is followed by the pairs of the left subtree, then those of the right subtree.  A ray that
+// visits both children pays for one line; a single internal child leaves a 64-byte hole.
+static void layout_sibling_pairs(PtBvh* b)
+{
+    const size_t n = b->nodes.size();
+    if (b->root < 0 || n == 0) return;
+    std::vector<int32_t> new_of(n, -1);
+    std::vector<int32_t> stack;
+    int32_t next = 2; // root alone in the first line
+    new_of[(size_t)b->root] = 0;
+    stack.push_back(b->root);
+    while (!stack.empty()) {
+        const int32_t i = stack.back();
+        stack.pop_back();
+        const PtNode& nd = b->nodes[(size_t)i];
+        if (nd.left >= 0 || nd.right >= 0) {
+            if (nd.left >= 0) new_of[(size_t)nd.left] = next;
+            if (nd.right >= 0) new_of[(size_t)nd.right] = next + 1;
+            next += 2;
+            if (nd.right >= 0) stack.push_back(nd.right); // left subtree first
+            if (nd.left >= 0) stack.push_back(nd.left);
+        }
+    }
+    std::vector<PtNode> out((size_t)next);
+    std::memset(out.data(), 0, out.size() * sizeof(PtNode));
+    for (size_t i = 0; i < out.size(); ++i) { // holes: empty boxes, never referenced
+        for (int a = 0; a < 3; ++a) { out[i].lo[a][0] = out[i].lo[a][1] = INFINITY; out[i].hi[a][0] = out[i].hi[a][1] = -INFINITY; }
+        out[i].left = out[i].right = -1;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (new_of[i] < 0) continue;
+        PtNode nd = b->nodes[i];
+        if (nd.left >= 0) nd.left = new_of[(size_t)nd.left];
+        if (nd.right >= 0) nd.right = new_of[(size_t)nd.right];
+        out[(size_t)new_of[i]] = nd;
+    }
+    b->nodes.swap(out);
+    b->root = 0;
+}
+
+// Leaf alignment: every leaf starts at a triangle slot that is a multiple of `align` (4 slots = 192 bytes: a leaf of up to four
+// 48-byte records then covers exactly two 128-byte lines instead of two or three).  Padding slots hold a never-hit record.
+static void layout_align_leaves(PtBvh* b, int align)
+{
+    if (align <= 1 || b->tris.empty()) return;
+    // leaves partition the slot range in order of their first slot
+    struct LeafRef { uint32_t first, count; int32_t* ref; };
+    std::vector<LeafRef> leaves;
+    auto note = [&](int32_t* ref) {
+        if (*ref < -1) { const uint32_t code = ~(uint32_t)*ref; leaves.push_back({code >> 3, code & 7u, ref}); }
+    };
+    for (PtNode& nd : b->nodes) { note(&nd.left); note(&nd.right); }
+    note(&b->root);
+    std::sort(leaves.begin(), leaves.end(), [](const LeafRef& x, const LeafRef& y) { return x.first < y.first; });
+    std::vector<PtTri> out;
+    out.reserve(b->tris.size() + leaves.size() * (size_t)(align - 1));
+    PtTri dummy;
+    std::memset(&dummy, 0, sizeof(dummy));
+    dummy.id = 0x7fffffff;
+    dummy.material = -1;
+    for (const LeafRef& lf : leaves) {
+        while (out.size() % (size_t)align) out.push_back(dummy);
+        const uint32_t nf = (uint32_t)out.size();
+        for (uint32_t k = 0; k < lf.count; ++k) out.push_back(b->tris[lf.first + k]);
+        *lf.ref = (int32_t)~((nf << 3) | lf.count);
+    }
+    b->tris.swap(out);
+}
+
+void pt_bvh_layout(PtBvh* b, int sibling_pairs, int leaf_align)
+{
+    if (sibling_pairs) layout_sibling_pairs(b);
+    layout_align_leaves(b, leaf_align);
+}
+
 void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max_depth, PtBvh* out)
 {
     out->nodes.clear();

@@ -19,6 +19,11 @@ struct PtBvh {
 // positions: n_tris*9 floats in global triangle order.  leaf_size 1..7, max_depth <= PT_MAX_STACK.
 void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max_depth, PtBvh* out);
 
+// Memory layout of the built tree (pt_bvh.cpp): sibling_pairs != 0 re-indexes the nodes so that sibling records share a
+// 128-byte line; leaf_align > 1 starts every leaf at a multiple of that many triangle slots (padding slots: id 0x7fffffff).
+// After it tris.size() may exceed the triangle count.
+void pt_bvh_layout(PtBvh* bvh, int sibling_pairs, int leaf_align);
+
 // Host mirror of the kernel's traversal over the product BVH (validation only, never on the render path).
 bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u,
                              float* v, int32_t* prim);

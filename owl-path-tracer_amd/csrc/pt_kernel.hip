@@ -95,10 +95,10 @@ __device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, 
 }
 
 // Moeller-Trumbore, two-sided, kTMin < t; ties in t go to the lower global id (order independent result).
-__device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slot, v3 o, v3 d, Hit& h)
+// tri_eval works on a record that is already in registers, so that a leaf step can issue the loads of all its triangles
+// before the first test (one memory round trip per leaf instead of one per triangle).
+__device__ __forceinline__ void tri_eval(const f32x4 a, const f32x4 b, const f32x4 c, int slot, v3 o, v3 d, Hit& h)
 {
-    const size_t tb = (size_t)(uint32_t)slot * sizeof(PtTri);
-    const f32x4 a = ldg4(tris, tb), b = ldg4(tris, tb + 16), c = ldg4(tris, tb + 32);
     v3 p0 = V(a.x, a.y, a.z), p1 = V(a.w, b.x, b.y), p2 = V(b.z, b.w, c.x);
     int id = __float_as_int(c.y);
     v3 e1 = p1 - p0, e2 = p2 - p0;
@@ -113,6 +113,37 @@ __device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slo
     if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > kTMin && (t < h.t || (t == h.t && id < h.id))) {
         h.t = t; h.u = u; h.v = v; h.id = id; h.slot = slot;
     }
+}
+__device__ __forceinline__ void tri_test(const PtTri* __restrict__ tris, int slot, v3 o, v3 d, Hit& h)
+{
+    const size_t tb = (size_t)(uint32_t)slot * sizeof(PtTri);
+    const f32x4 a = ldg4(tris, tb), b = ldg4(tris, tb + 16), c = ldg4(tris, tb + 32);
+    tri_eval(a, b, c, slot, o, d, h);
+}
+// All triangles of one leaf: the records of the first PT_LEAF_PREFETCH triangles are requested together, the tests follow.
+#ifndef PT_LEAF_PREFETCH
+#define PT_LEAF_PREFETCH 4
+#endif
+__device__ __forceinline__ void leaf_test(const PtTri* __restrict__ tris, int first, int count, v3 o, v3 d, Hit& h)
+{
+#if PT_LEAF_PREFETCH == 0
+    for (int k = 0; k < count; ++k) tri_test(tris, first + k, o, d, h);
+#else
+    f32x4 ra[PT_LEAF_PREFETCH], rb[PT_LEAF_PREFETCH], rc[PT_LEAF_PREFETCH];
+    // unconditional loads (lanes with fewer triangles re-read their last one): one basic block, so all requests are in flight
+    // before the first wait; with a per-triangle predicate the compiler waits inside each predicated block
+#pragma unroll
+    for (int k = 0; k < PT_LEAF_PREFETCH; ++k) {
+        const int kk = k < count ? k : count - 1;
+        const size_t tb = (size_t)(uint32_t)(first + kk) * sizeof(PtTri);
+        ra[k] = ldg4(tris, tb); rb[k] = ldg4(tris, tb + 16); rc[k] = ldg4(tris, tb + 32);
+    }
+#pragma unroll
+    for (int k = 0; k < PT_LEAF_PREFETCH; ++k) {
+        if (k < count) tri_eval(ra[k], rb[k], rc[k], first + k, o, d, h);
+    }
+    for (int k = PT_LEAF_PREFETCH; k < count; ++k) tri_test(tris, first + k, o, d, h); // leaf_size > PT_LEAF_PREFETCH only
+#endif
 }
 
 // One BVH-node step for a lane: test both children, descend into the nearer hit child, push the other.
@@ -611,6 +642,20 @@ struct WaveCtx {
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
+    int ray_low, min_batch, full_batch; // shading-batch thresholds (PT_RAY_LOW, PT_MIN_BATCH, 64; pt_set_option "tune1".."tune3")
+    int n_run;      // slots of this wave with a (pixel, chunk) running
+    int adapt;      // 1: the thresholds follow n_run: a wave with few running pixels shades small batches instead of waiting for its slowest ray, and
+                    // keeps stepping nodes while half of the lanes that started a burst still want to (1/8 shard of C4 391 -> 350 ms, 1/64 251 -> 214 ms)
+    __device__ __forceinline__ void retune(int mb0, int rl0, int fb0)
+    {
+        if (!adapt) return;
+        const int third = n_run / 3;
+        const int lo = third < 4 ? 4 : third;
+        min_batch = lo < mb0 ? lo : mb0;
+        ray_low = lo < rl0 ? lo : rl0;
+        const int two = 2 * third < 8 ? 8 : 2 * third;
+        full_batch = two < fb0 ? two : fb0;
+    }
     __device__ __forceinline__ int wrap(int i) const { return i >= ns ? i - ns : i; } // i < 2 * ns
 };
 
@@ -620,12 +665,12 @@ enum { PICK_NONE = 0, PICK_HIT = 1, PICK_MISS = 2 };
 __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
 {
     const bool miss_ok = !w.miss_blocked;
-    if (w.hit_count >= PT_WAVE) return PICK_HIT;
-    if (miss_ok && w.miss_count >= PT_WAVE) return PICK_MISS;
-    if (w.ray_count < PT_RAY_LOW) {
+    if (w.hit_count >= w.full_batch) return PICK_HIT;
+    if (miss_ok && w.miss_count >= w.full_batch) return PICK_MISS;
+    if (w.ray_count < w.ray_low) {
         // the ray queue is about to run dry: a half-full shading pass is cheaper than idle traversal lanes (traversal is ~80 %
         // of a wave's time, shading ~12 %)
-        const bool h = w.hit_count >= PT_MIN_BATCH, m = miss_ok && w.miss_count >= PT_MIN_BATCH;
+        const bool h = w.hit_count >= w.min_batch, m = miss_ok && w.miss_count >= w.min_batch;
         if (h && (!m || w.hit_count >= w.miss_count)) return PICK_HIT;
         if (m) return PICK_MISS;
     }
@@ -655,7 +700,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     const bool mine = lane < n;
     if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
     int ps_slot = 0;
-    bool to_ray = false, to_hit = false, to_wait = false, died = false;
+    bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
     if (mine) {
         ps_slot = (int)q[w.wrap(q_head + lane)];
         uint32_t pid = GF(S_PIX, ps_slot);
@@ -702,6 +747,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                     ticket = take_ticket(P); // in flight while finish_chunk stores the pixel's state
                     finish_chunk(P, chunk, px, py, ps.rng, color);
                     have_pixel = false;
+                    ended = true;
                 }
             } else {
                 to_ray = true;
@@ -714,6 +760,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                     died = true;
                 } else if (start_chunk(P, ticket, chunk, px, py, ps.rng, color)) {
                     have_pixel = true;
+                    started = true;
                     s = 0;
                 } else {
                     to_wait = true; // predecessor chunk still running somewhere: keep the ticket, poll again later
@@ -760,6 +807,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     w.hit_count += popc64(m_hit);
     w.miss_count += popc64(m_wait);
     w.n_dead += popc64(m_dead);
+    w.n_run += popc64(__ballot(started)) - popc64(__ballot(ended));
     if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? n : 0; } // [17]: rays shaded after the queue ran dry (wind-down)
     // a pass that only polled unpublished tickets must not be repeated before the wave has done something else
     w.miss_blocked = IS_MISS && n > 0 && popc64(m_wait) == n;
@@ -811,6 +859,12 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
         lstate[S_RNG * ns + i] = PT_FRESH;
     }
     w.miss_blocked = false;
+    w.min_batch = P.tune[1] > 0 ? P.tune[1] : PT_MIN_BATCH;
+    w.ray_low = P.tune[2] > 0 ? P.tune[2] : PT_RAY_LOW;
+    w.full_batch = P.tune[3] > 0 ? P.tune[3] : PT_WAVE;
+    const int mb0 = w.min_batch, rl0 = w.ray_low, fb0 = w.full_batch;
+    w.n_run = 0;
+    w.adapt = P.tune[5] != 2; // option "adaptive" (default on; 2 = off)
     w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
     int n_parked = 0, n_rounds = 0;
     Counters cn;
@@ -837,9 +891,11 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
         }
         if (pick == PICK_HIT) {
             shade_pass<COUNT, false>(P, w, lane, cn);
+            w.retune(mb0, rl0, fb0);
             if (COUNT) cn.cyc[3] += __builtin_amdgcn_s_memtime() - t0;
         } else if (pick == PICK_MISS) {
             shade_pass<COUNT, true>(P, w, lane, cn);
+            w.retune(mb0, rl0, fb0);
             if (COUNT) cn.cyc[4] += __builtin_amdgcn_s_memtime() - t0;
         } else if (starving) {
             // every live slot of this wave waits for a work item that another wave is still rendering
@@ -914,9 +970,10 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
                             o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
                             d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
                             inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            cur = P.root;
+                            // a scene of <= leaf_size triangles has a leaf as its root: it starts as the stashed leaf
+                            cur = P.root >= 0 ? P.root : PT_DONE;
                             sp = 0;
-                            pend = PT_DONE;
+                            pend = P.root < PT_DONE ? P.root : PT_DONE;
                             h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
                         }
                         w.ray_head = w.wrap(w.ray_head + take);
@@ -944,8 +1001,12 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
                     // (1 x 1 -> 2 x up to 3: C4 626 -> 599 ms, its 1/8 shard 480 -> 435 ms, C2 98 -> 91 ms).
                     if (__ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) == 0ull) {
 #if PT_NODE_KEEP > 0
-                      for (int burst = 0; burst < PT_NODE_BURSTS; ++burst) {
-                        if (burst > 0 && (popc64(__ballot(cur >= 0)) < PT_NODE_KEEP || __ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) != 0ull)) break;
+                      // a sparse wave (adapt): the bursts go on while at least half of the lanes that started them want another step, up to twice as many
+                      const int n_node0 = popc64(m_node);
+                      const int keep = w.adapt && n_node0 < 2 * PT_NODE_KEEP ? (n_node0 + 1) / 2 : PT_NODE_KEEP;
+                      const int max_bursts = w.adapt && n_node0 < PT_NODE_KEEP ? 2 * PT_NODE_BURSTS : PT_NODE_BURSTS;
+                      for (int burst = 0; burst < max_bursts; ++burst) {
+                        if (burst > 0 && (popc64(__ballot(cur >= 0)) < keep || __ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) != 0ull)) break;
 #endif
 #pragma unroll
                         for (int rep = 0; rep < PT_NODE_REPS; ++rep) {
@@ -985,10 +1046,8 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
                     if (pend < PT_DONE) { // every triangle of the pending leaf in one step: the leaf lanes are cleared for good
                         const uint32_t code = ~(uint32_t)pend;
                         const int firstt = (int)(code >> 3), count = (int)(code & 7u);
-                        for (int k = 0; k < count; ++k) {
-                            if (COUNT) ++cn.tris;
-                            tri_test(tris, firstt + k, o, d, h);
-                        }
+                        if (COUNT) cn.tris += (uint32_t)count;
+                        leaf_test(tris, firstt, count, o, d, h);
                         if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
                             pend = cur;
                             if (sp > 0) {
@@ -1246,7 +1305,7 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         *state_words_per_block = 0;
     } else {
         fn = count ? (const void*)pt_render_wave_kernel<true> : (const void*)pt_render_wave_kernel<false>;
-        int n = want_ns < PT_WAVE ? PT_WAVE : (want_ns > 255 ? 255 : want_ns);
+        int n = want_ns < 16 ? 16 : (want_ns > 255 ? 255 : want_ns);
         *block = PT_WAVE;
         *ns = n;
         *lds_bytes = pt_wave_lds_bytes(stack_entries, n);

@@ -93,4 +93,5 @@ struct PtKernelParams {
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];
+    int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
 };

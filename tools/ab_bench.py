@@ -8,13 +8,17 @@ import ptamd
 ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
 
+PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align")  # builder / layout options: before upload_scene
+NOT_OPTIONS = ("spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c4"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     opts = dict(a.split("=") for a in sys.argv[3:])
     ctx = B.Context(0)
     for k, v in opts.items():
-        if k in ("leaf_size", "max_bvh_depth"):
+        if k in PRE_UPLOAD:
             ctx.set_option(k, int(v))
     if which == "c4":
         _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "dragon.json"))
@@ -32,7 +36,7 @@ def main():
     if "shard_rank" in opts:
         ctx.set_pixel_shard(int(opts["shard_rank"]), int(opts.get("shard_world", 8)), int(opts.get("shard_tile", 16)))
     for k, v in opts.items():
-        if k not in ("leaf_size", "max_bvh_depth", "spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v"):
+        if k not in PRE_UPLOAD and k not in NOT_OPTIONS:
             ctx.set_option(k, int(v))
     ms = []
     for _ in range(reps):
@@ -64,6 +68,15 @@ def main():
         cen["winddown_time_share"] = round(cen["winddown_ticks"] / max(1, cyc["total"]), 4)
         cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
         print(json.dumps(cen))
+    if opts.get("chain"):
+        # per-ray turnaround of the longest sample chain: the cost pre-pass counted the rays of the first 8 samples of every pixel
+        # (saturating at 255), so the most expensive pixel traces about max_cost / 8 * spp sequential rays in kernel_ms
+        _, _, cost = ctx.read_queue(W * H)
+        if cost.size:
+            mx = int(cost.max()); p999 = float(np.percentile(cost, 99.9))
+            print(json.dumps({"chain": {"max_cost_per_8spp": mx, "p99.9_cost": p999, "longest_chain_rays": int(mx / 8 * spp),
+                                        "us_per_ray_longest_chain": round(min(ms) * 1e3 / max(1.0, mx / 8 * spp), 2),
+                                        "us_per_ray_p99.9_chain": round(min(ms) * 1e3 / max(1.0, p999 / 8 * spp), 2)}}))
     if opts.get("timeline"):
         print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
