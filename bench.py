@@ -10,8 +10,14 @@ environment (intensity 0), light from the 'areaLight' quad.  One "step" = one co
 
 N > 1: one process per GPU; every rank holds a scene replica and renders the pixel tiles it owns (16x16 tiles dealt
 round-robin; pixels are independent, samples of one pixel are NOT -- the reference threads one RNG stream through all
-samples of a pixel), then ONE RCCL reduce (sum) of the float3 framebuffer to rank 0.  Total work is fixed => "strong".
-Prints one JSON line on rank 0.
+samples of a pixel), then ONE RCCL reduce (sum) of the float3 framebuffer to rank 0 -- inside the library (pt_comm_init_rank +
+pt_render, include/mi355pt.h); torch.distributed only carries the 128-byte communicator id, the barrier and the max over ranks.
+Total work is fixed => "strong".
+
+Timed span of a step: pt_render = kernels + reduce + D2H of the complete float3 frame into pinned host memory on
+rank 0.  After the timed loop every rank checks that no watchdog fired and rank 0 checks the frame against the checksum of the
+parity-tested image (tests/golden/c4_frame_crc.json; `--write-golden` regenerates it, tests/test_gpu_parity.py pins the same
+render against the oracle).  Prints one JSON line on rank 0.
 """
 import argparse
 import json
@@ -47,18 +53,43 @@ def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
     return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
 
 
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+GOLDEN_CRC = os.path.join(ROOT, "tests", "golden", "c4_frame_crc.json")
+
+
+def kernel_fingerprint():
+    """sha256 of the render kernel's sources: PMC numbers are only quoted for the build they were measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("pt_kernel.hip", "pt_device.h", "pt_types.h"):
+        with open(os.path.join(ROOT, "owl-path-tracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(world):
     """HBM/fabric bytes per launch of the render kernel from rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE x 1024 is the byte count for this kernel's 64-byte gathers: profiles/r01_fetch_calibration.md).
-    PMC cannot be collected from inside the timed run, so the figure is read from the committed summary; null if absent/N>1."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world != 1 or not os.path.exists(path):
+    PMC cannot be collected from inside the timed run, so the figure is read from the committed summary of the profiling run
+    (tools/profile_round.sh writes it together with the fingerprint of the kernel sources); null when the kernel has changed
+    since, when the file is absent, or for N > 1."""
+    if world != 1 or not os.path.exists(TRAFFIC_JSON):
         return None
     try:
-        with open(path) as f:
-            return int(json.load(f)["traffic_bytes_per_launch"])
+        with open(TRAFFIC_JSON) as f:
+            d = json.load(f)
+        if d.get("kernel_fingerprint") != kernel_fingerprint():
+            return None
+        return int(d["traffic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
+
+
+def frame_crc(rgb):
+    import zlib
+
+    return zlib.crc32(np.ascontiguousarray(rgb, np.float32).tobytes()) & 0xFFFFFFFF
 
 
 def effective_cpus():
@@ -101,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-launch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--write-golden", action="store_true", help="store the checksum of this run's frame as the expected one (after the parity tests passed)")
     args = ap.parse_args()
 
     import torch
@@ -119,25 +151,28 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render path)")
     torch.cuda.set_device(local_rank)
-    D.init(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+    D.init(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm: barrier + max over ranks only
 
     scene_io, mats, ents = build_workload()  # also loads the package
     from owl_path_tracer_amd.pyhost import binding as B
 
     ctx = B.Context(local_rank)
     ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
-    ctx.set_pixel_shard(rank, world, D.TILE)
+    if world > 1:
+        # the library owns the communicator: rank 0 draws the id (ncclGetUniqueId), the launcher's group carries the 128 bytes
+        box = [B.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init_rank(box[0], rank, world)  # also sets this rank's pixel shard (16x16 tiles, round-robin)
     if args.spp_per_launch:
         ctx.set_option("spp_per_launch", args.spp_per_launch)
     cam = B.to_camera_data([4.0, 2.5, 0.0], [0.0, 0.75, 0.0], [0.0, 1.0, 0.0], 50.0, W, H)
 
     dev = torch.device("cuda", local_rank)
-    fb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    frame = B.PinnedFrame(W, H) if rank == 0 else None  # pinned host memory, like the reference's framebuffer (owl.hpp:108-111)
 
     def step():
-        ctx.render_device(cam, W, H, SPP, DEPTH, fb.data_ptr(), None, stream)
-        D.reduce_framebuffer(fb, dst=0)  # the one collective: float3 framebuffer over xGMI (no-op for one rank)
+        # pt_render: this rank's tiles -> (N > 1) ONE RCCL reduce of the float3 framebuffer onto rank 0 -> D2H on rank 0; blocking
+        ctx.render_into(cam, W, H, SPP, DEPTH, frame.rgb if rank == 0 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -147,8 +182,7 @@ def main():
 
     # instrumented pass (untimed): work counters for the algorithmic-bytes figure
     ctx.set_option("count", 1)
-    ctx.render_device(cam, W, H, SPP, DEPTH, fb.data_ptr(), None, stream)
-    torch.cuda.synchronize()
+    step()
     cst = ctx.stats()
     ctx.set_option("count", 0)
     own_pixels = int(B.shard_pixels(W, H, D.TILE, rank, world).size)
@@ -156,25 +190,42 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms, prepass_ms = [], []
+    kernel_ms, prepass_ms, step_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
-        fst = ctx.stats()  # HIP events recorded on the launch stream: first launch .. end, and end of pre-pass + sort
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        fst = ctx.stats()  # HIP events recorded on the launch stream: first launch .. end, and end of pre-pass + sort; raises if a watchdog fired
         kernel_ms.append(fst["kernel_ms"])
         prepass_ms.append(fst["prepass_ms"])
     fence()
     elapsed = time.perf_counter() - t0
+    ctx.synchronize()  # PT_E_HIP -> PtError if any wave's watchdog fired during the timed frames: an incomplete image is not a result
+    med_ms = float(np.median(step_ms))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, med_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, med_ms = float(t[0].item()), float(t[1].item())
     st = ctx.stats()
+
+    crc = frame_crc(frame.rgb) if rank == 0 else None
+    if rank == 0:
+        if args.write_golden:
+            with open(GOLDEN_CRC, "w") as f:
+                json.dump({"workload": "C4 stand-in 1920x1080x1024spp depth 16 (bench.py)", "crc32_float3_frame": crc,
+                           "mean": float(np.mean(frame.rgb, dtype=np.float64))}, f)
+        frame_check = "no golden checksum"
+        if os.path.exists(GOLDEN_CRC):
+            want = json.load(open(GOLDEN_CRC))["crc32_float3_frame"]
+            if want != crc:
+                raise SystemExit("bench.py: the rendered frame (crc32 %08x) is not the parity-tested image (crc32 %08x)" % (crc, want))
+            frame_check = "crc32 %08x == tests/golden/c4_frame_crc.json" % crc
 
     if rank == 0:
         launches = max(1, st["launches"])
-        k_ms = float(np.mean(kernel_ms))  # per frame on this rank
-        p_ms = float(np.mean(prepass_ms))  # of which: cost pre-pass launch (PREPASS_SPP samples per pixel) + queue sort
+        k_ms = float(np.median(kernel_ms))  # per frame on this rank
+        p_ms = float(np.median(prepass_ms))  # of which: cost pre-pass launch (PREPASS_SPP samples per pixel) + queue sort
         alg_frame = algorithmic_bytes(cst, own_pixels)  # this rank's frame, both launches
         # The dominant kernel launch is the main one (launch 2 of 2 per frame): samples PREPASS_SPP.. of every pixel.  Counted work
         # is per frame; per-sample work does not depend on the sample index, so the main launch carries (SPP - PREPASS_SPP) / SPP.
@@ -191,6 +242,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median": round(med_ms, 3),
+            "timed_span": "pt_render: kernels + RCCL reduce (N > 1) + D2H of the float3 frame into pinned host memory on rank 0",
+            "frame_check": frame_check,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -198,7 +252,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C4 dragon.json on the 871400-triangle stand-in (dragon.obj.scene is a missing blob), 1920x1080, 1024 spp, "
                                    "max_path_depth 16, environment intensity 0, areaLight emission 30",
-                       "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer" % (D.TILE, D.TILE, world),
+                       "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer inside the library (pt_comm_init_rank)" % (D.TILE, D.TILE, world),
                        "kernel": "wavefront-scheduled megakernel; per frame: cost pre-pass launch (%d spp) + queue sort + one persistent main launch" % PREPASS_SPP, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
                        "bvh_depth": int(st["bvh_depth"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -213,6 +267,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene_io, mats, ents, cam.as_array())
         print(json.dumps(out), flush=True)
 
+    if frame is not None:
+        frame.free()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

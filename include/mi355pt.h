@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 #define PT_MAT_FLOATS 17 /* material_data: device_global.hpp:19-36, 68 bytes, field order kept */
 
 enum {
@@ -126,7 +126,43 @@ int pt_render(pt_ctx* ctx, const pt_camera* cam, int32_t width, int32_t height, 
  * in HBM at d_out_rgb (device pointer, W*H*3 floats) for the caller's RCCL reduce.  d_out_rgba8 optional. */
 int pt_render_device(pt_ctx* ctx, const pt_camera* cam, int32_t width, int32_t height, int32_t max_samples, int32_t max_path_depth,
                      void* d_out_rgb, void* d_out_rgba8, void* stream);
+/* Waits for the last pt_render_device (its stream and the context's) and returns PT_E_HIP if a wave's watchdog fired during
+ * it (the image is then incomplete); pt_get_stats reports the same. */
 int pt_synchronize(pt_ctx* ctx);
+
+/* ---- N GPUs: pixel tiles sharded over ranks + ONE RCCL sum-reduce of the float3 framebuffer onto rank 0 (pt_comm.cpp) ----
+ * No reference counterpart (the reference is single-GPU: create_context(nullptr, 1), application.cpp:62); for N > 1 these
+ * replace the render + read-back of application.cpp:363-369.  Every pixel has exactly one non-zero contributor, so the
+ * N-GPU frame is bit-identical to the 1-GPU frame.  The library owns the communicator (librccl.so.1, resolved on first use).
+ *
+ * (a) One process per GPU.  Rank 0 calls pt_comm_get_unique_id; the 128 bytes reach the other ranks by the launcher's
+ *     means; every rank calls pt_comm_init_rank (collective; also sets the rank's pixel shard, tile 16).  From then on
+ *     pt_render renders the shard, reduces, and fills out_rgb / out_rgba8 on rank 0 only (other ranks may pass NULL). */
+#define PT_COMM_ID_BYTES 128
+int pt_comm_get_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
+int pt_comm_init_rank(pt_ctx* ctx, const uint8_t id[PT_COMM_ID_BYTES], int32_t rank, int32_t world_size);
+int pt_comm_destroy(pt_ctx* ctx);
+/* The reduce by itself, asynchronous on `stream` (NULL = the context's stream), in place on device buffers as filled by
+ * pt_render_device (n_pixels*3 floats; d_rgba8 optional, n_pixels uint32).  A no-op without a communicator. */
+int pt_reduce_framebuffer(pt_ctx* ctx, void* d_rgb, void* d_rgba8, int64_t n_pixels, void* stream);
+/* Pinned host memory for the frame, like the reference's framebuffer (owlBufferGetPointer, owl.hpp:108-111). */
+void* pt_host_alloc(size_t bytes);
+void pt_host_free(void* p);
+
+/* (b) One process, N GPUs (`pt_main --gpus N`): N contexts + ncclCommInitAll; scene calls fan out to every device (full
+ *     replica each), pt_group_render = shards + one reduce + read-back from device 0.  devices NULL = 0..n-1. */
+typedef struct pt_group pt_group;
+pt_group* pt_group_create(const int32_t* devices, int32_t n);   /* NULL on failure; pt_last_error(NULL) has the reason */
+void pt_group_destroy(pt_group* g);
+int32_t pt_group_size(const pt_group* g);
+pt_ctx* pt_group_ctx(pt_group* g, int32_t i);
+const char* pt_group_last_error(const pt_group* g);
+int pt_group_upload_scene(pt_group* g, const pt_mesh* meshes, int32_t n_meshes, const float* materials, int32_t n_materials,
+                          const pt_texture* textures, int32_t n_textures, const int32_t* material_texture, const pt_env* env);
+int pt_group_set_materials(pt_group* g, const float* materials, int32_t n_materials);
+int pt_group_set_option(pt_group* g, const char* key, int64_t value);
+int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t height, int32_t max_samples, int32_t max_path_depth,
+                    float* out_rgb, uint32_t* out_rgba8);
 
 /* Tuning / test options (all have working defaults; none changes an image):
  *   "kernel" 2 (default, wavefront-scheduled) | 1 (lane per pixel);  "count" 0/1: instrumented kernel that fills pt_stats;

@@ -9,9 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mi355pt.h"
-#include "pt_bvh.h"
-#include "pt_types.h"
+#include "pt_internal.h"
 
 extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
                                        hipStream_t stream, int count);
@@ -25,64 +23,10 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
 extern "C" int pt_debug_block(void);
 
 namespace {
-
 std::string g_create_error;
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct HostTexture {
-    int w = 0, h = 0;
-    std::vector<uint32_t> px;
-};
-
 } // namespace
 
-struct pt_ctx {
-    int device = -1;
-    bool host_only = false;
-    int num_cus = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr; // evm: after the cost pre-pass and the queue sort
-    bool ev_pending = false;
-    std::string err;
-
-    // host copies
-    PtBvh bvh;
-    std::vector<PtShade> shade;
-    std::vector<float> materials; // n * PT_MAT_STRIDE
-    int n_materials = 0;
-    std::vector<int32_t> material_texture;
-    std::vector<HostTexture> textures;
-    pt_env env{};
-    HostTexture env_map;
-    bool have_scene = false;
-
-    // device
-    DevBuf d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket;
-    std::vector<void*> d_textures;
-
-    // pixel queue
-    int q_w = 0, q_h = 0, q_rank = 0, q_world = 1, q_tile = 16;
-    int rank = 0, world = 1, tile = 16;
-    uint32_t n_pixels = 0;
-    bool queue_valid = false;
-
-    // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = 16, schedule = 1, prepass_spp = 8, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1;
-    int tune[8] = {};
-
-    pt_stats stats{};
-    int last_launches = 0;
-    bool last_sorted = false;
-    int last_w = 0, last_h = 0;
-    size_t lap_ticks_ofs = 0;
-    int last_chunks = 0;
-};
-
-namespace {
+namespace pti {
 
 int fail(pt_ctx* c, int code, const char* fmt, ...)
 {
@@ -96,12 +40,6 @@ int fail(pt_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
-#define HIP_TRY(c, call)                                                                              \
-    do {                                                                                              \
-        hipError_t e__ = (call);                                                                      \
-        if (e__ != hipSuccess) return fail(c, PT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
-    } while (0)
-
 int ensure(pt_ctx* c, DevBuf& b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
@@ -113,6 +51,12 @@ int ensure(pt_ctx* c, DevBuf& b, size_t bytes)
     b.cap = bytes;
     return PT_OK;
 }
+
+} // namespace pti
+using pti::ensure;
+using pti::fail;
+
+namespace {
 
 int upload(pt_ctx* c, DevBuf& b, const void* src, size_t bytes)
 {
@@ -232,6 +176,21 @@ void fill_params(pt_ctx* c, PtKernelParams& P)
 
 } // namespace
 
+namespace pti {
+// After the render stream has drained: did a wave's watchdog fire (pt_kernel.hip, PT_WATCHDOG_ROUNDS)?  The image is then incomplete.
+int check_watchdog(pt_ctx* c)
+{
+    if (c->kernel != 2 || !c->d_laps.p || !c->flag_pending) return PT_OK;
+    uint32_t wd = 0;
+    HIP_TRY(c, hipMemcpy(&wd, c->d_laps.p, 4, hipMemcpyDeviceToHost));
+    c->flag_pending = false;
+    c->watchdog_fired = wd != 0;
+    if (wd) return fail(c, PT_E_HIP, "render kernel watchdog fired (scheduler made no progress); the image is incomplete");
+    return PT_OK;
+}
+} // namespace pti
+using pti::check_watchdog;
+
 extern "C" {
 
 int pt_abi_version(void) { return PT_ABI_VERSION; }
@@ -281,6 +240,7 @@ void pt_destroy(pt_ctx* c)
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        (void)pt_comm_destroy(c);
         DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
                           &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
         for (DevBuf* b : bufs) release(*b);
@@ -401,6 +361,8 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         c->textures[i].h = textures[i].height;
         c->textures[i].px.assign(textures[i].rgba8, textures[i].rgba8 + (size_t)textures[i].width * textures[i].height);
     }
+    for (int i = 0; i < (int)c->material_texture.size(); ++i)
+        if (c->material_texture[i] >= n_textures) return fail(c, PT_E_INVALID, "material %d: texture index %d out of range (%d textures)", i, c->material_texture[i], n_textures);
     pack_materials(c, materials, n_materials);
     pt_env def{};
     copy_env(c, env ? env : &def);
@@ -591,7 +553,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         // Layout (never a plain store in a cache line that also holds device-scope atomics): [0] watchdog flag | +256 B: ring fill
         // counters (n_chunks + 1, + the pre-pass's spare) | 256-B aligned: diagnostics timelines of the two launches.
         c->lap_ticks_ofs = ((256 + (size_t)(n_chunks + 3) * 4 + 255) / 256) * 256;
-        const size_t laps_bytes = c->lap_ticks_ofs + ((size_t)(n_chunks + 1) * 3 + 128) * 8 * 2;
+        const size_t laps_bytes = c->lap_ticks_ofs + ((size_t)PT_LAP_REGION(n_chunks) + (size_t)PT_LAP_REGION(1)) * 8;
         if ((rc = ensure(c, c->d_laps, laps_bytes))) return rc;
         if ((rc = ensure(c, c->d_ring, (size_t)c->n_pixels * 4 * (size_t)n_chunks))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_laps.p, 0, laps_bytes, stream));
@@ -655,7 +617,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             P.pixel_ids = l == 0 ? (const uint32_t*)c->d_pixels.p : (const uint32_t*)c->d_sorted.p;
             P.cost_out = l == 0 ? (uint8_t*)c->d_cost.p : nullptr;
             P.dbg_start = (l == 1 && c->latency) ? (uint32_t*)c->d_dbg_start.p : nullptr;
-            P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs) + (l == 0 ? 3 * (n_chunks + 1) + 128 : 0);
+            P.lap_ticks = (unsigned long long*)((char*)c->d_laps.p + c->lap_ticks_ofs) + (l == 0 ? PT_LAP_REGION(n_chunks) : 0); // the pre-pass's block follows the main launch's
             P.ring_tail = (uint32_t*)c->d_laps.p + 64 + (l == 0 ? n_chunks : 0); // the pre-pass only uses its [1]: the spare counter
             if (l == 0) { // one chunk per pixel
                 P.chunk_spp = P.sample_count;
@@ -680,6 +642,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;
+    c->flag_pending = true;
+    c->last_stream = stream;
     c->last_launches = n_launch;
     c->last_sorted = sorted;
     c->last_w = W;
@@ -693,18 +657,22 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     return PT_OK;
 }
 
+
 int pt_synchronize(pt_ctx* c)
 {
     if (!c) return PT_E_INVALID;
     if (c->host_only) return PT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->last_stream && c->last_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->last_stream)); // pt_render_device on a caller's stream
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return PT_OK;
+    return check_watchdog(c);
 }
 
 int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max_samples, int32_t max_depth, float* out_rgb, uint32_t* out_rgba8)
 {
-    if (!c || !cam || !out_rgb) return PT_E_INVALID;
+    // with a communicator attached (pt_comm_init_rank) only rank 0 receives the frame; the other ranks may pass NULL
+    const bool root = !c || !c->comm || c->comm_rank == 0;
+    if (!c || !cam || (root && !out_rgb)) return PT_E_INVALID;
     if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: the HIP render path is required and there is no CPU fallback");
     if (W <= 0 || H <= 0) return fail(c, PT_E_INVALID, "bad render size %dx%d", W, H);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -714,13 +682,14 @@ int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max
     if (out_rgba8 && (rc = ensure(c, c->d_out8, npx * 4))) return rc;
     rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, nullptr);
     if (rc) return rc;
-    uint32_t wd = 0;
-    if (c->kernel == 2 && c->d_laps.p) HIP_TRY(c, hipMemcpyAsync(&wd, c->d_laps.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
-    if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
+    // N ranks: the one collective of the path - RCCL sum-reduce of the float3 framebuffer onto rank 0 (pt_comm.cpp)
+    if (c->comm && (rc = pt_reduce_framebuffer(c, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, (int64_t)npx, nullptr))) return rc;
+    if (root) {
+        HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
+        if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (wd) return fail(c, PT_E_HIP, "render kernel watchdog fired (scheduler made no progress); the image is incomplete");
-    return PT_OK;
+    return check_watchdog(c);
 }
 
 int pt_get_stats(pt_ctx* c, pt_stats* out)
@@ -729,6 +698,8 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
     if (!c->host_only && c->ev_pending) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipEventSynchronize(c->ev1));
+        int wrc = check_watchdog(c);
+        if (wrc) return wrc;
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.kernel_ms = ms;
@@ -815,10 +786,14 @@ int64_t pt_debug_read_laps(pt_ctx* c, uint64_t* ticks, int64_t cap)
     if (!c || !ticks) return PT_E_INVALID;
     if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_read_laps needs the GPU");
     if (c->kernel != 2 || !c->d_laps.p) return 0;
-    const int64_t n = std::min<int64_t>(cap, 3 * (c->last_chunks + 1) + 128);
+    const int nt = 3 * (c->last_chunks + 1);
+    std::vector<uint64_t> blk((size_t)PT_LAP_REGION(c->last_chunks));
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(ticks, (char*)c->d_laps.p + c->lap_ticks_ofs, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(blk.data(), (char*)c->d_laps.p + c->lap_ticks_ofs, blk.size() * 8, hipMemcpyDeviceToHost));
+    int64_t n = 0; // the timeline, then the 64 latency accumulators, without the padding between them
+    for (int i = 0; i < nt && n < cap; ++i) ticks[n++] = blk[(size_t)i];
+    for (int i = 0; i < 64 && n < cap; ++i) ticks[n++] = blk[(size_t)PT_LAP_DIAG_OFS(c->last_chunks) + i];
     return n;
 }
 

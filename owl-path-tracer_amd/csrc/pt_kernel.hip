@@ -398,10 +398,20 @@ __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& p
 // over all laps let expensive pixels fall ~20 ms further behind per lap; a slot keeping its pixel for all samples leaves
 // 25-28 % of the wave time to a wind-down with ~8 busy lanes - profiles/r01_summary.md).
 //
-// Cross-wave hand-off (MI355X_MICROARCH.md "Valid forms", sc1 row): the finishing lane stores the state with
-// agent-scope relaxed atomics (write-through sc1 stores), waits vmcnt(0), then takes a ring position and stores the
-// entry (sc1).  The starting lane polls ITS ring cell with an sc1 load and only then issues the sc1 loads of the state (control
-// dependency).  No fence, no spinning: a slot whose cell is not published yet keeps its ticket and polls again in a later pass.
+// Cross-wave hand-off.  This is the sc1 form of MI355X_MICROARCH.md "Valid forms" (first row of its table), not a C++ release /
+// acquire pair, and it is valid only because every condition of that row holds here:
+//   * the handed-off bytes (rng_state[pid], accum[3 pid ..]) are written ONLY by 4-byte agent-scope stores (global_store_dword sc1,
+//     write-through to the fabric) and read ONLY by 4-byte agent-scope loads to registers (global_load_dword sc1: never served from
+//     this CU's vL1D, never flat_): st_agent / ld_agent below; hipMalloc memory; one wave per workgroup;
+//   * the storing wave executes s_waitcnt vmcnt(0) after those stores (the inline asm in finish_chunk; a workgroup is one wave,
+//     so "every storing wave" is this wave), and only then stores the flag - the ring cell - again sc1;
+//   * the consumer learns of it by an sc1 load poll of THAT cell, and the polling lane issues its loads of the bytes only after
+//     its poll has matched (start_chunk returns before them otherwise: a control dependency in the same lane).
+// An agent-scope acquire per poll would also be correct but is 2-3x slower per hop and, with hundreds of pollers, costs the
+// whole chip bandwidth (same section, "Invalid forms"); a release would write back the XCD's L2.  Counters that are updated with
+// device-scope atomics (ticket heads, ring fills, the diagnostics accumulators) sit on cache lines that nothing stores to
+// plainly (pt_api.cpp lays them out in 256-byte blocks; PT_LAP_DIAG_OFS) - a plain store into such a line made publications
+// disappear in round 1.  No spinning: a slot whose cell is not published yet keeps its ticket and polls again in a later pass.
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(gp(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(gp(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -455,8 +465,8 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
     if (c == 0 && P.dbg_start) { // diagnostics (tools/ab_bench.py latency=1): first-chunk duration by cost class of the pixel
         const uint32_t dt = (uint32_t)wall_clock64() - gp(P.dbg_start)[pid];
         const uint32_t cls = gp(P.dbg_cost)[pid] >> 2 < 31u ? gp(P.dbg_cost)[pid] >> 2 : 31u;
-        atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + cls, (unsigned long long)dt);
-        atomicAdd(P.lap_ticks + 3 * (P.n_chunks + 1) + 32 + cls, 1ull);
+        atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + cls, (unsigned long long)dt);
+        atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + 32 + cls, 1ull);
     }
     if (last_chunk && P.timeline) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
         if (take_agent(P.ring_tail + P.n_chunks) == P.n_pixels - 1u) {
@@ -885,16 +895,20 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
         }
         const bool starving = w.ray_count == 0 && n_parked == 0;
         const int pick = pick_pass(w, starving);
-        if (++n_rounds > PT_WATCHDOG_ROUNDS) { // scheduler bug guard: never hang the GPU
+        // scheduler bug guard: never hang the GPU.  n_rounds counts the rounds since this wave last shaded a ray (waiting for another
+        // wave's chunk is legitimate and can take long: the cap is ~30 s of nothing but polls and sleeps)
+        if (++n_rounds > PT_WATCHDOG_ROUNDS) {
             if (lane == 0) gp(P.error_flag)[0] = 1u;
             break;
         }
         if (pick == PICK_HIT) {
             shade_pass<COUNT, false>(P, w, lane, cn);
+            n_rounds = 0; // hits are always running paths: progress
             w.retune(mb0, rl0, fb0);
             if (COUNT) cn.cyc[3] += __builtin_amdgcn_s_memtime() - t0;
         } else if (pick == PICK_MISS) {
             shade_pass<COUNT, true>(P, w, lane, cn);
+            if (!w.miss_blocked) n_rounds = 0; // the pass did more than poll unpublished tickets
             w.retune(mb0, rl0, fb0);
             if (COUNT) cn.cyc[4] += __builtin_amdgcn_s_memtime() - t0;
         } else if (starving) {
@@ -927,10 +941,17 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_rende
                 }
             }
             bool first = true;
-            int n_retire_passes = 0;
+            int n_retire_passes = 0, n_inner = 0;
             unsigned long long t1 = 0;
             if (COUNT) { t1 = __builtin_amdgcn_s_memtime(); cn.cyc[5] += t1 - t0; }
             for (;;) {
+                // every iteration steps or retires at least one lane, and a ray needs a few thousand steps at most: far beyond that
+                // the traversal state is inconsistent (e.g. a corrupt node reference) - give up loudly instead of spinning
+                if (++n_inner > (1 << 22)) {
+                    if (lane == 0) gp(P.error_flag)[0] = 1u;
+                    n_rounds = PT_WATCHDOG_ROUNDS;
+                    break;
+                }
                 // idle lanes (pslot < 0) always hold cur == PT_DONE and pend == PT_DONE
                 const unsigned long long m_leaf = __ballot(pend < PT_DONE);               // lanes with a stashed leaf to test
                 const unsigned long long m_done = __ballot(cur == PT_DONE) & __ballot(pslot >= 0) & ~m_leaf;

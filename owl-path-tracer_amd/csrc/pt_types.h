@@ -50,6 +50,10 @@ struct PtCounters {
 };
 
 #define PT_MAX_TAIL_CHUNKS 20
+// Diagnostics block of one launch (u64 units, 256-byte aligned): the chunk timeline (3 x (n_chunks + 1) values, plain stores), then -
+// on cache lines of their own, because they are updated with device-scope atomics - 64 first-chunk latency accumulators.
+#define PT_LAP_DIAG_OFS(nc) (((3 * ((nc) + 1)) + 31) & ~31)
+#define PT_LAP_REGION(nc) (PT_LAP_DIAG_OFS(nc) + 64)
 
 struct PtKernelParams {
     const PtNode* nodes;

@@ -4,7 +4,9 @@
 // <scene>_<test.name>_<attribute_name>(<value>).png in the CWD.  The render itself goes through the C-ABI (mi355pt.h).
 //
 // Optional flags (defaults reproduce the reference, which has no CLI): --assets DIR, --out DIR, --settings FILE, --device N
-// (-1: load + build only, no render), --dump-scene FILE (binary dump of the ingested scene for the loader tests).
+// (-1: load + build only, no render), --gpus N (devices 0..N-1 of this node: pixel tiles sharded over them, one RCCL reduce of the
+// float3 framebuffer onto device 0 - pt_group_* in mi355pt.h; the image is bit-identical to --gpus 1), --dump-scene FILE (binary
+// dump of the ingested scene for the loader tests).
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -61,14 +63,15 @@ struct App {
     host::Settings settings;
     host::Scene scene;
     std::vector<float> materials; // n * 17
-    pt_ctx* ctx = nullptr;
+    pt_ctx* ctx = nullptr;     // device 0's context (all of them for --gpus 1)
+    pt_group* group = nullptr; // --gpus N: N contexts + the library's RCCL communicator
     pt_camera cam{};
     std::string out_dir;
 };
 
 void check(App& a, int rc, const char* what)
 {
-    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + pt_last_error(a.ctx));
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + (a.group ? pt_group_last_error(a.group) : pt_last_error(a.ctx)));
 }
 
 // render_frame, application.cpp:363-371
@@ -78,7 +81,8 @@ void render_frame(App& a, const std::string& values)
     const int W = a.settings.buffer_size[0], H = a.settings.buffer_size[1];
     std::vector<float> rgb((size_t)W * H * 3);
     std::vector<uint32_t> rgba((size_t)W * H);
-    check(a, pt_render(a.ctx, &a.cam, W, H, a.settings.max_samples, a.settings.max_path_depth, rgb.data(), rgba.data()), "pt_render");
+    if (a.group) check(a, pt_group_render(a.group, &a.cam, W, H, a.settings.max_samples, a.settings.max_path_depth, rgb.data(), rgba.data()), "pt_group_render");
+    else check(a, pt_render(a.ctx, &a.cam, W, H, a.settings.max_samples, a.settings.max_path_depth, rgb.data(), rgba.data()), "pt_render");
     pt_stats st;
     pt_get_stats(a.ctx, &st);
     std::string name = a.settings.scene + "_" + a.settings.test.name + "_" + a.settings.test.attribute_name + "(" + values + ").png";
@@ -119,7 +123,8 @@ void test_loop(App& a)
             if (attr >= 0) mat[attr] = v;
             values = fmt1(v);
         }
-        check(a, pt_set_materials(a.ctx, a.materials.data(), (int32_t)a.scene.materials.size()), "pt_set_materials"); // reset_field
+        if (a.group) check(a, pt_group_set_materials(a.group, a.materials.data(), (int32_t)a.scene.materials.size()), "pt_group_set_materials");
+        else check(a, pt_set_materials(a.ctx, a.materials.data(), (int32_t)a.scene.materials.size()), "pt_set_materials"); // reset_field
         render_frame(a, values);
     }
 }
@@ -135,7 +140,7 @@ int main(int argc, char** argv)
         std::string assets = std::string(cwd) + "/assets"; // Main.cpp:17
         std::string settings_path, dump;
         a.out_dir = cwd;
-        int device = 0;
+        int device = 0, gpus = 0; // gpus 0: flag not given, single context as in the reference
         for (int i = 1; i < argc; ++i) {
             std::string k = argv[i];
             auto next = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value for " + k); return std::string(argv[++i]); };
@@ -143,6 +148,7 @@ int main(int argc, char** argv)
             else if (k == "--out") a.out_dir = next();
             else if (k == "--settings") settings_path = next();
             else if (k == "--device") device = std::atoi(next().c_str());
+            else if (k == "--gpus") gpus = std::atoi(next().c_str());
             else if (k == "--dump-scene") dump = next();
             else if (k == "--convert-png" || k == "--convert-hdr") { // codec self-test hooks: decode with our reader, re-encode with our writer
                 std::string in = next(), out = next();
@@ -214,12 +220,21 @@ int main(int argc, char** argv)
         env.intensity = a.settings.environment_intensity;
         env.map = {env_img.width, env_img.height, env_img.rgba.empty() ? nullptr : env_img.rgba.data()};
 
-        pt_config cfg{device, 0};
-        a.ctx = pt_create(&cfg);
-        if (!a.ctx) throw std::runtime_error(std::string("pt_create: ") + pt_last_error(nullptr));
+        if (gpus < 0) throw std::runtime_error("--gpus needs a positive count");
         if (meshes.empty()) throw std::runtime_error("no geometries"); // application.cpp:133
-        check(a, pt_upload_scene(a.ctx, meshes.data(), (int32_t)meshes.size(), a.materials.data(), (int32_t)a.scene.materials.size(),
-                                 textures.data(), (int32_t)textures.size(), nullptr, &env), "pt_upload_scene");
+        if (gpus >= 1 && device >= 0) { // devices 0..gpus-1: a scene replica on each, the library's communicator across them
+            a.group = pt_group_create(nullptr, gpus);
+            if (!a.group) throw std::runtime_error(std::string("pt_group_create: ") + pt_last_error(nullptr));
+            a.ctx = pt_group_ctx(a.group, 0);
+            check(a, pt_group_upload_scene(a.group, meshes.data(), (int32_t)meshes.size(), a.materials.data(), (int32_t)a.scene.materials.size(),
+                                           textures.data(), (int32_t)textures.size(), nullptr, &env), "pt_group_upload_scene");
+        } else {
+            pt_config cfg{device, 0};
+            a.ctx = pt_create(&cfg);
+            if (!a.ctx) throw std::runtime_error(std::string("pt_create: ") + pt_last_error(nullptr));
+            check(a, pt_upload_scene(a.ctx, meshes.data(), (int32_t)meshes.size(), a.materials.data(), (int32_t)a.scene.materials.size(),
+                                     textures.data(), (int32_t)textures.size(), nullptr, &env), "pt_upload_scene");
+        }
         pt_to_camera_data(a.scene.camera.look_from, a.scene.camera.look_at, a.scene.camera.look_up, a.scene.camera.vertical_fov,
                           a.settings.buffer_size[0], a.settings.buffer_size[1], &a.cam); // parse_camera -> to_camera_data
         pt_stats st;
@@ -228,7 +243,8 @@ int main(int argc, char** argv)
                      (unsigned long long)st.n_triangles, meshes.size(), (unsigned long long)st.bvh_nodes, (unsigned long long)st.bvh_depth, st.bvh_build_ms);
         if (device >= 0) test_loop(a);
         else std::fprintf(stderr, "--device -1: scene loaded and BVH built, no render\n");
-        pt_destroy(a.ctx); // Main.cpp:30
+        if (a.group) pt_group_destroy(a.group);
+        else pt_destroy(a.ctx); // Main.cpp:30
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -61,7 +61,11 @@ class Stats(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upload_scene", "pt_set_materials", "pt_set_environment",
            "pt_set_pixel_shard", "pt_shard_pixels", "pt_render", "pt_render_device", "pt_synchronize", "pt_set_option", "pt_get_stats",
-           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps"]
+           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps",
+           "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_framebuffer", "pt_host_alloc", "pt_host_free",
+           "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_ctx", "pt_group_last_error", "pt_group_upload_scene",
+           "pt_group_set_materials", "pt_group_set_option", "pt_group_render"]
+PT_COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -101,8 +105,62 @@ def lib():
     L.pt_debug_read_queue.restype = C.c_int64
     L.pt_debug_read_laps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
     L.pt_debug_read_laps.restype = C.c_int64
+    u8p = C.POINTER(C.c_uint8)
+    L.pt_comm_get_unique_id.argtypes = [u8p]
+    L.pt_comm_init_rank.argtypes = [C.c_void_p, u8p, C.c_int32, C.c_int32]
+    L.pt_comm_destroy.argtypes = [C.c_void_p]
+    L.pt_reduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.pt_host_alloc.restype = C.c_void_p
+    L.pt_host_alloc.argtypes = [C.c_size_t]
+    L.pt_host_free.restype = None
+    L.pt_host_free.argtypes = [C.c_void_p]
+    L.pt_group_create.restype = C.c_void_p
+    L.pt_group_create.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+    L.pt_group_destroy.restype = None
+    L.pt_group_destroy.argtypes = [C.c_void_p]
+    L.pt_group_size.argtypes = [C.c_void_p]
+    L.pt_group_ctx.restype = C.c_void_p
+    L.pt_group_ctx.argtypes = [C.c_void_p, C.c_int32]
+    L.pt_group_last_error.restype = C.c_char_p
+    L.pt_group_last_error.argtypes = [C.c_void_p]
+    L.pt_group_upload_scene.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int32, fp, C.c_int32, C.POINTER(Texture), C.c_int32,
+                                        C.POINTER(C.c_int32), C.POINTER(Env)]
+    L.pt_group_set_materials.argtypes = [C.c_void_p, fp, C.c_int32]
+    L.pt_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.pt_group_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
+
+
+def comm_unique_id():
+    """128 opaque bytes from rank 0 (ncclGetUniqueId inside the library) for pt_comm_init_rank on every rank."""
+    buf = (C.c_uint8 * PT_COMM_ID_BYTES)()
+    rc = lib().pt_comm_get_unique_id(buf)
+    if rc < 0:
+        raise PtError("pt_comm_get_unique_id failed (%d): %s" % (rc, lib().pt_last_error(None).decode()))
+    return bytes(buf)
+
+
+class PinnedFrame:
+    """W x H x 3 float32 (and optionally W x H uint32) in pinned host memory from pt_host_alloc, viewed as numpy arrays."""
+
+    def __init__(self, W, H, want_rgba8=False):
+        self._p = lib().pt_host_alloc(W * H * 12)
+        self._p8 = lib().pt_host_alloc(W * H * 4) if want_rgba8 else None
+        if not self._p or (want_rgba8 and not self._p8):
+            raise PtError("pt_host_alloc failed")
+        self.rgb = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_float)), shape=(H, W, 3))
+        self.rgba8 = np.ctypeslib.as_array(C.cast(self._p8, C.POINTER(C.c_uint32)), shape=(H, W)) if want_rgba8 else None
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.rgb = None
+            lib().pt_host_free(self._p)
+            self._p = None
+        if getattr(self, "_p8", None):
+            self.rgba8 = None
+            lib().pt_host_free(self._p8)
+            self._p8 = None
 
 
 def _vec3(v):
@@ -222,6 +280,22 @@ class Context:
                                     rgba.ctypes.data_as(C.POINTER(C.c_uint32)) if rgba is not None else None), "pt_render")
         return rgb, rgba
 
+    def render_into(self, cam, W, H, spp, max_depth, rgb, rgba8=None):
+        """pt_render into caller-owned arrays (e.g. a PinnedFrame); rgb may be None on the non-root ranks of a communicator."""
+        self._check(lib().pt_render(self._h, C.byref(cam), W, H, spp, max_depth, rgb.ctypes.data_as(C.POINTER(C.c_float)) if rgb is not None else None,
+                                    rgba8.ctypes.data_as(C.POINTER(C.c_uint32)) if rgba8 is not None else None), "pt_render")
+
+    def comm_init_rank(self, unique_id, rank, world):
+        buf = (C.c_uint8 * PT_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(lib().pt_comm_init_rank(self._h, buf, rank, world), "pt_comm_init_rank")
+
+    def comm_destroy(self):
+        self._check(lib().pt_comm_destroy(self._h), "pt_comm_destroy")
+
+    def reduce_framebuffer(self, d_rgb, d_rgba8, n_pixels, stream=None):
+        self._check(lib().pt_reduce_framebuffer(self._h, C.c_void_p(d_rgb), C.c_void_p(d_rgba8) if d_rgba8 else None, n_pixels,
+                                                C.c_void_p(stream) if stream else None), "pt_reduce_framebuffer")
+
     def render_device(self, cam, W, H, spp, max_depth, d_out_rgb, d_out_rgba8=None, stream=None):
         self._check(lib().pt_render_device(self._h, C.byref(cam), W, H, spp, max_depth, C.c_void_p(d_out_rgb),
                                            C.c_void_p(d_out_rgba8) if d_out_rgba8 else None, C.c_void_p(stream) if stream else None),
@@ -256,7 +330,7 @@ class Context:
         n = lib().pt_debug_read_laps(self._h, t.ctypes.data_as(C.POINTER(C.c_uint64)), t.size)
         if n < 0:
             self._check(int(n), "pt_debug_read_laps")
-        m = (int(n) - 128) // 3
+        m = (int(n) - 64) // 3
         ms = lambda x: round((int(x) - int(t[0])) / 1e5, 2)
         return {"last_done_ms": [ms(x) for x in t[1:m]], "last_start_ms": [ms(x) for x in t[m + 1:2 * m]], "last_entry": [int(x) for x in t[2 * m + 1:3 * m]],
                 "first_chunk_ticks_by_cost_class": [int(x) for x in t[3 * m:3 * m + 32]], "first_chunk_count_by_cost_class": [int(x) for x in t[3 * m + 32:3 * m + 64]]}

@@ -5,7 +5,10 @@ The reference is single-GPU (create_context(nullptr, 1), path_tracer/src/applica
 device.cu:229-243), so the frame is sharded by pixel tile, never by sample.  Every rank renders the tiles
 `pt_shard_pixels(W, H, tile, rank, world)` into a zero-initialised W*H*3 float buffer; because every pixel has exactly one
 non-zero contributor the sum over ranks is exact, i.e. the N-GPU image is bit-identical to the 1-GPU image.
-On ROCm torch.distributed's "nccl" backend IS RCCL (xGMI inside a node); the CPU tests run the same code over gloo.
+On the GPU the reduce is the LIBRARY's (pt_comm_init_rank + pt_render / pt_group_render: RCCL inside libmi355pt.so, pt_comm.cpp);
+bench.py uses torch.distributed only for the rendezvous (the 128-byte communicator id), the barrier and the max over ranks.
+`reduce_framebuffer` below is the same sum over gloo for the CPU tests of the sharding logic (tests/test_multi_rank_cpu.py), where
+no GPU and therefore no RCCL exists.
 """
 import os
 
@@ -35,7 +38,7 @@ def init(backend=None, device=None):
 
 
 def reduce_framebuffer(fb, dst=0):
-    """The one collective of the render path: sum of the float3 framebuffer to rank `dst` (24.9 MB at 1920x1080)."""
+    """CPU-test stand-in (gloo) for the library's RCCL reduce: sum of the float3 framebuffer to rank `dst`."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb

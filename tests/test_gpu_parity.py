@@ -507,3 +507,48 @@ def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
     S = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 4096, 16, 160, 6)
     print("C5 (counted) kernel_ms=%.1f Msamples/s=%.1f rays/sample=%.2f" % (st["kernel_ms"], W * H * 4096 / st["kernel_ms"] / 1e3, st["rays"] / st["samples"]))
+
+
+def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
+    """A scene of <= leaf_size triangles has a LEAF as BVH root (pt_bvh.cpp); the wavefront kernel used to spin on it (round-1 advisor
+    finding).  One quad + sky, both kernels, against the oracle."""
+    quad = dict(vertices=np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32), normals=np.array([[0, 1, 0]] * 4, np.float32),
+                texcoords=np.zeros((4, 2), np.float32), indices=np.array([[0, 1, 2], [0, 2, 3]], np.int32))
+    mat = np.zeros((1, 17), np.float32)
+    mat[0, :3] = (0.7, 0.6, 0.5); mat[0, 4] = 0.3; mat[0, 5] = 0.5; mat[0, 7] = 0.6; mat[0, 13] = 1.45
+    ents = [(quad, 0)]
+    env = B.make_env(use_auto=True, intensity=1.0)
+    gpu.upload_scene(ents, mat, env=env)
+    assert gpu.stats()["bvh_nodes"] == 0
+    W, H = 96, 64
+    cam = B.to_camera_data([0, 1.5, 3], [0, 0, 0], [0, 1, 0], 45, W, H)
+    S = orc.Scene(scene_io.flatten_scene(ents, [("quad", mat[0], "")]))
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 8)
+    for k in (2, 1):
+        gpu.set_option("kernel", k)
+        got, _ = gpu.render(cam, W, H, 16, 8)
+        assert_bitwise(got, want, "one quad, kernel %d" % k)
+    gpu.set_option("kernel", 2)
+
+
+def test_library_communicator_single_rank(gpu, cornell):
+    """The library's own RCCL path on one GPU: unique id, ncclCommInitRank(world 1), pt_render with the reduce in it, pinned
+    output - bit-identical to the plain render.  (N > 1 through the same calls: tests/test_host_main.py, bench.py --gpus N.)"""
+    _upload(gpu, cornell)
+    W, H = 96, 80
+    cam = _cam(cornell, W, H)
+    want, want8 = gpu.render(cam, W, H, 16, 16, want_rgba8=True)
+    ctx = B.Context(0)
+    try:
+        _upload(ctx, cornell)
+        uid = B.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        ctx.comm_init_rank(uid, 0, 1)
+        fr = B.PinnedFrame(W, H, want_rgba8=True)
+        ctx.render_into(cam, W, H, 16, 16, fr.rgb, fr.rgba8)
+        assert_bitwise(np.array(fr.rgb), want, "render with a world-1 communicator")
+        np.testing.assert_array_equal(np.array(fr.rgba8), want8)
+        ctx.comm_destroy()
+        fr.free()
+    finally:
+        ctx.close()

@@ -203,3 +203,97 @@ def test_pt_main_end_to_end_matches_oracle(tmp_path, orc, scene_io):
         _, want8, _ = S.render(cam, orc.make_env(color=(1, 1, 1), intensity=0.0), 64, 64, 8, 16, want_rgba8=True)
         got = np.asarray(Image.open(tmp_path / ("cornell-box_sweep_metallic(%.1f).png" % v))).view(np.uint32).reshape(64, 64)
         np.testing.assert_array_equal(got, want8)
+
+
+def _write_rle_hdr(path, rgbe):
+    """Radiance RGBE file with RLE scanlines (the encoding image_buffer.cpp:36-58 reads through stb)."""
+    H, W = rgbe.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (H, W))
+        for y in range(H):
+            f.write(bytes([2, 2, W >> 8, W & 255]))
+            for c in range(4):
+                row, x = rgbe[y, :, c], 0
+                while x < W:
+                    run = 1
+                    while x + run < W and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, row[x]]))
+                        x += run
+                    else:
+                        n = min(W - x, 5)
+                        f.write(bytes([n]) + bytes(row[x:x + n]))
+                        x += n
+
+
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_pt_main_environment_hdr_and_texture_end_to_end(tmp_path, orc, scene_io):
+    """assets/environment.hdr (RLE RGBE) and a PNG texture through the real entry point on the GPU -
+    application.cpp:160 -> image_buffer.cpp:36-58 (stb tone map + vertical flip) -> device.cu:23-39 (miss shader lookup), and
+    application.cpp:225-246 -> device.cu:75-94 (texture).  The oracle gets the environment map as the product's own decoder
+    produces it (the decoder itself is checked against the stb formula in test_png_and_hdr_codecs)."""
+    from PIL import Image
+
+    a = tmp_path / "assets"
+    shutil.copytree(ASSETS, a)
+    os.makedirs(a / "cube-textures")
+    tex = scene_io.checker_texture()
+    Image.fromarray(np.ascontiguousarray(tex[::-1]).view(np.uint8).reshape(64, 64, 4)).save(a / "cube-textures" / "cube.png")
+    # sky gradient + sun + ground, enough dynamic range for the tone map to matter, long runs for the RLE
+    EW, EH = 256, 128
+    yy, xx = np.mgrid[0:EH, 0:EW]
+    lum = np.where(yy < EH // 2, 0.3 + 1.7 * (1 - yy / (EH / 2)), 0.08 + 0.1 * ((xx // 16 + yy // 16) % 2))
+    sun = np.exp(-(((xx - 180) / 6.0) ** 2 + ((yy - 24) / 6.0) ** 2)) * 40.0
+    rgbf = np.stack([lum * 0.9 + sun, lum * 1.0 + sun * 0.9, lum * 1.3 + sun * 0.6], -1).astype(np.float64)
+    m = rgbf.max(-1)
+    e = np.ceil(np.log2(np.maximum(m, 1e-30))).astype(np.int32)
+    rgbe = np.zeros((EH, EW, 4), np.uint8)
+    rgbe[..., :3] = np.clip(rgbf / np.ldexp(1.0, e)[..., None] * 256.0, 0, 255).astype(np.uint8)
+    rgbe[..., 3] = (e + 128).astype(np.uint8)
+    _write_rle_hdr(a / "environment.hdr", rgbe)
+    s = json.load(open(os.path.join(ASSETS, "configs", "c1_cube.json")))
+    s.update(buffer_size=[160, 96], max_samples=32, max_path_depth=6, environment_use=True, environment_auto=False, environment_intensity=1.0)
+    (a / "settings.json").write_text(json.dumps(s))
+    out = _run(["--assets", str(a), "--out", str(tmp_path)])
+    png = tmp_path / "cube_bench_roughness(0.2).png"
+    assert png.exists(), out.stderr
+    got = np.asarray(Image.open(png)).view(np.uint32).reshape(96, 160)
+    _run(["--convert-hdr", str(a / "environment.hdr"), str(tmp_path / "env.png")])
+    env = np.ascontiguousarray(np.asarray(Image.open(tmp_path / "env.png"))[::-1]).view(np.uint32).reshape(EH, EW)  # flip: image_buffer.cpp:50-55
+    assert len(np.unique(env)) > 50
+    sc = scene_io.load_scene_dir(str(a), "cube")
+    S = orc.Scene(scene_io.flatten_scene(sc["entities"], sc["materials"], {0: tex}))
+    c = sc["camera"]
+    cam = orc.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], 160, 96)
+    _, want8, st = S.render(cam, orc.make_env(use_map=True, intensity=1.0, env_map=env), 160, 96, 32, 6, want_rgba8=True, want_counters=True)
+    assert st["env_misses"] > 1000
+    np.testing.assert_array_equal(got, want8)
+
+
+@pytest.mark.gpu
+def test_pt_main_gpus_flag_is_bit_identical(tmp_path):
+    """`pt_main --gpus N` (pt_group_*: pixel tiles over N devices + the library's RCCL reduce onto device 0) writes the same PNG
+    as the single-context path.  N = 1 always runs; N = 2 and N = all devices when the box has them."""
+    a = tmp_path / "assets"
+    shutil.copytree(ASSETS, a)
+    s = json.load(open(os.path.join(ASSETS, "configs", "c2_cornell-box.json")))
+    s.update(buffer_size=[200, 120], max_samples=48)
+    (a / "settings.json").write_text(json.dumps(s))
+    name = "cornell-box_%s_%s(%.1f).png" % (s["test"]["name"], s["test"]["attribute_name"], s["test"]["values"][0])
+    ref_dir = tmp_path / "ref"
+    os.makedirs(ref_dir)
+    _run(["--assets", str(a), "--out", str(ref_dir)])
+    want = open(ref_dir / name, "rb").read()
+    nd = _device_count()
+    for n in sorted({1, min(2, nd), nd}):
+        d = tmp_path / ("g%d" % n)
+        os.makedirs(d)
+        _run(["--assets", str(a), "--out", str(d), "--gpus", str(n)])
+        assert open(d / name, "rb").read() == want, "--gpus %d differs from the single-context image" % n
