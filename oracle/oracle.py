@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
+# PT_ORACLE_LIB: the tolerance-calibration build (libpt_oracle_hostlibm.so, oracle/Makefile) in a process of its own
+_LIB_PATH = os.environ.get("PT_ORACLE_LIB") or os.path.join(_HERE, "libpt_oracle.so")
 
 MAT_FLOATS = 17
 MAT_KEYS = [

@@ -241,6 +241,24 @@ void orc_dm_batch(int fn, const float* x, const float* y, float* out, int64_t n)
     }
 }
 
+#ifdef ORC_HOST_LIBM
+/* TOLERANCE-CALIBRATION BUILD ONLY (oracle/Makefile target libpt_oracle_hostlibm.so, tests/test_tolerance_calibration.py):
+ * the same render loop with the host's libm transcendentals instead of the dm_* routines, compiled with -ffp-contract=fast.
+ * BASELINE.md section 4 asks for exactly this pair - a second CPU build that differs the way an independent toolchain
+ * (CUDA libdevice, nvcc's own fma choices) would - as the noise floor for the stated OptiX tolerance.  The orc_dm_* entry
+ * points above keep exporting the deterministic routines. */
+#define dm_sincos(x, s, c) sincosf((x), (s), (c))
+#define dm_sin(x) sinf(x)
+#define dm_cos(x) cosf(x)
+#define dm_tan(x) tanf(x)
+#define dm_atan(x) atanf(x)
+#define dm_atan2(y, x) atan2f((y), (x))
+#define dm_asin(x) asinf(x)
+#define dm_log(x) logf(x)
+#define dm_exp(x) expf(x)
+#define dm_pow(x, y) powf((x), (y))
+#endif
+
 /* ------------------------------------------------------------------------------------------ */
 /* vec3 (owl::vec3f stand-in; component-wise ops, see SURVEY 8(c) caveat on owl::normalize)    */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Builds tests/golden/furnace_reference.json from the only rendered OUTPUTS the reference repository holds:
+thesis/assets/furnace-test/furnace_test_<test.name>_roughness(<v>).png (1024x1024 RGBA8, written by the reference's own
+`<scene>_<test.name>_<attribute_name>(<value>).png` naming, application.cpp:370 / application.hpp:101-105).
+
+A furnace test renders the object `sphere` of assets/sphere.json (camera (3,1,0) -> (0,1,0), vfov 50) inside a uniform white
+environment.  The sphere is convex, so every path is: camera ray -> one BSDF sample -> miss; a pixel's value is the directional
+albedo E[f |cos| / pdf] of the material at that pixel's viewing angle, which depends only on the normalised distance from the
+silhouette centre.  The fixture therefore stores, per image, the mean 8-bit value in ten rings of normalised radius plus the
+centre statistics - data, a few hundred bytes; the PNGs themselves stay in the reference.
+
+Only the images whose material is unambiguous from the file name AND the shipped source are used: `diffuse` (sphere.json as
+shipped, roughness 0 / 1), `metallic` (metallic 1, roughness 0) and `specular_transmission` (transmission 1, roughness 0).  The
+`metallic_ndf` / `metallic_vndf` / `coupled` / `uncoupled` images document alternative code states the thesis compares (the
+shipped specular lobe samples the NDF but uses the VNDF pdf, disney_specular.cuh:144,157) and match none of them exactly.
+
+Run in the build container (needs /root/reference): python tests/golden/make_furnace_fixture.py
+"""
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+SRC = "/root/reference/thesis/assets/furnace-test"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "furnace_reference.json")
+USE = {"diffuse_roughness(0.0)": dict(roughness=0.0), "diffuse_roughness(1.0)": dict(roughness=1.0),
+       "metallic_roughness(0.0)": dict(metallic=1.0, roughness=0.0),
+       "specular_transmission_roughness(0.0)": dict(specular_transmission=1.0, roughness=0.0, specular_transmission_roughness=0.0)}
+
+
+def main():
+    out = {"source": "thesis/assets/furnace-test/*.png of jctemp/owl-path-tracer (reference-rendered outputs)", "images": {}}
+    sil = None
+    for key, mat in USE.items():
+        im = np.asarray(Image.open(os.path.join(SRC, "furnace_test_%s.png" % key))).astype(np.float64)
+        H, W = im.shape[:2]
+        assert (im[..., 3] == 255).all() and (im[..., 0] == im[..., 1]).all() and (im[..., 0] == im[..., 2]).all()
+        g = im[..., 0]
+        ys, xs = np.nonzero(g < 255)
+        if ys.size > 100000:  # the sphere is visible: silhouette half-height in pixels
+            sil = (ys.max() - ys.min() + 1) / 2.0
+        yy, xx = np.mgrid[0:H, 0:W]
+        rr = np.sqrt((yy - (H - 1) / 2.0) ** 2 + (xx - (W - 1) / 2.0) ** 2) / (sil if sil else 302.0)
+        rings = [float(g[(rr >= a) & (rr < a + 0.1)].mean()) for a in np.arange(0, 1.0, 0.1)]
+        c = g[H // 2 - 20:H // 2 + 20, W // 2 - 20:W // 2 + 20]
+        out["images"][key] = {"material_overrides": mat, "size": [W, H], "ring_means": rings, "centre_mean": float(c.mean()), "centre_std": float(c.std()),
+                              "min": float(g.min()), "fraction_255": float((g == 255).mean())}
+    out["silhouette_half_height_px"] = sil
+    out["silhouette_radius_over_half_image"] = sil / 512.0
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

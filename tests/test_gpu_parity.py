@@ -423,6 +423,14 @@ def _subset_check(gpu_img, S, orc, cam, env, W, H, spp, depth, n_pix, seed):
     assert_bitwise(gpu_img[ys, xs], sub[ys, xs], "pixel subset at full spp")
 
 
+def _whole_frame_check(gpu, S, orc, cam, env, W, H, spp, depth, what):
+    """EVERY pixel of the full-size frame at low spp, bit for bit: every pixel's camera rays and first bounces walk the deep BVH of
+    the full-size scene (the full-spp comparison can only afford a pixel subset on the CPU)."""
+    got, _ = gpu.render(cam, W, H, spp, depth)
+    want, _, _ = S.render(_ocam(orc, cam), env, W, H, spp, depth)
+    assert_bitwise(got, want, "%s: whole frame %dx%d at %d spp" % (what, W, H, spp))
+
+
 def test_c2_cornell_full_size(gpu, orc, cornell):
     """BASELINE C2: cornell-box.json, 512x512, 256 spp, depth 16."""
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
@@ -457,6 +465,12 @@ def test_c4_dragon_standin_full_size(gpu, orc, scene_io, procedural):
     flat = scene_io.flatten_scene(ents, mats)
     S = orc.Scene(flat)
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 1024, 16, 600, 4)
+    # the frame bench.py times is this frame: its checksum is the one bench.py asserts after its timed loop
+    import json, zlib
+    want_crc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c4_frame_crc.json")))["crc32_float3_frame"]
+    assert zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF == want_crc, "C4 frame differs from tests/golden/c4_frame_crc.json (re-run bench.py --write-golden after an intended change)"
+    _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C4")    # single launch, queue order
+    _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 32, 16, "C4")   # cost pre-pass + sorted queue + rings
     # shards: rank 3 of 8 renders only its tiles, and exactly the full image's values there
     gpu.set_pixel_shard(3, 8, 16)
     part, _ = gpu.render(cam, W, H, 1024, 16)
@@ -481,6 +495,7 @@ def test_c3_mitsuba_standin_full_size(gpu, orc, scene_io, procedural):
     st = gpu.stats()
     S = orc.Scene(scene_io.flatten_scene(ents, mats))
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 512, 16, 800, 5)
+    _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 8, 16, "C3")
     assert a.mean() > 0.05
     print("C3 kernel_ms=%.1f Msamples/s=%.1f" % (st["kernel_ms"], W * H * 512 / st["kernel_ms"] / 1e3))
 
@@ -506,6 +521,7 @@ def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
     assert np.isfinite(a).all() and st["env_misses"] > 0 and st["samples"] == W * H * 4096
     S = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 4096, 16, 160, 6)
+    _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C5")
     print("C5 (counted) kernel_ms=%.1f Msamples/s=%.1f rays/sample=%.2f" % (st["kernel_ms"], W * H * 4096 / st["kernel_ms"] / 1e3, st["rays"] / st["samples"]))
 
 
@@ -552,3 +568,20 @@ def test_library_communicator_single_rank(gpu, cornell):
         fr.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)"])
+def test_furnace_against_reference_rendered_images_gpu(gpu, orc, scene_io, procedural, key):
+    """The HIP path against the reference-rendered furnace images (tests/furnace_common.py; tests/test_oracle_render.py holds the
+    same check for the oracle) and, bit for bit, against the oracle on the same frame."""
+    import furnace_common as F
+
+    ents, mats = F.setup(scene_io, procedural, key)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=1.0))
+    cam = B.to_camera_data([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, F.W, F.H)
+    rgb, rgba = gpu.render(cam, F.W, F.H, F.SPP, F.DEPTH, want_rgba8=True)
+    F.check(key, rgba)
+    S = orc.Scene(scene_io.flatten_scene(ents, mats))
+    want, want8, _ = S.render(_ocam(orc, cam), orc.make_env(color=(1, 1, 1), intensity=1), F.W, F.H, F.SPP, F.DEPTH, want_rgba8=True)
+    assert_bitwise(rgb, want, "furnace " + key)
+    np.testing.assert_array_equal(rgba, want8)

@@ -174,3 +174,18 @@ def test_golden_regression(orc, cube):
     cam = _cam(orc, cube["camera"], 32, 32)
     rgb, _, _ = S.render(cam, orc.make_env(use_auto=True, intensity=1), 32, 32, 8, 4)
     np.testing.assert_array_equal(rgb, np.load(path))
+
+
+@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)"])
+def test_furnace_against_reference_rendered_images(orc, scene_io, procedural, key):
+    """The oracle against the ONLY rendered outputs the reference repository holds (thesis/assets/furnace-test): radial profile of
+    the 8-bit image, ring by ring (tests/furnace_common.py).  This pins, with data produced by the reference itself: the camera, the
+    miss shader, the diffuse lobe (sampling, eval, pdf), the mirror limit of the specular and glass lobes, `f |cos| / pdf`
+    accumulation and the truncating x256 quantiser assumed for owl::make_rgba (0.976 -> a 249/250 mix, mean 249.4, as in the PNG)."""
+    import furnace_common as F
+
+    ents, mats = F.setup(scene_io, procedural, key)
+    S = orc.Scene(scene_io.flatten_scene(ents, mats))
+    cam = orc.to_camera_data([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, F.W, F.H)
+    _, rgba, _ = S.render(cam, orc.make_env(color=(1, 1, 1), intensity=1), F.W, F.H, F.SPP, F.DEPTH, want_rgba8=True)
+    F.check(key, rgba)
