@@ -20,6 +20,8 @@
 //  pt_render_kernel (option kernel=1): the simple persistent lane-per-pixel form kept for A/B measurements.
 //
 // The traversal stack is stack[level][lane] in LDS: bank = lane % 32 whatever the level, conflict-free.
+#include <cstdlib>
+
 #include "pt_device.h"
 #include "pt_types.h"
 
@@ -30,6 +32,9 @@ using namespace ptd;
 #define PT_WAVE 64
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 4
+#endif
+#ifndef PT_COUNT_WAVES_PER_EU
+#define PT_COUNT_WAVES_PER_EU 2 // the instrumented instance gets 256 VGPRs (see pt_render_wave_kernel)
 #endif
 #ifndef PT_WATCHDOG_ROUNDS
 #define PT_WATCHDOG_ROUNDS 20000000 // wave-loop rounds (shading passes + traversal phases) before a wave gives up; a C5 frame needs ~2e5 per wave
@@ -832,7 +837,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 // kernel rendered wrong pixels in round 1 (both instrumented instances, identical source otherwise; never the 128-VGPR product
 // instance, which does not spill).  pt_render refuses to launch any instance that needs scratch (pt_kernel_geometry).
 template <bool COUNT>
-__global__ void __launch_bounds__(PT_WAVE, COUNT ? 2 : PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
+__global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
 {
     // The parameter block lives in HBM and is read with scalar loads where it is used.  Passed by value it arrives as
     // s_load_dwordx16 tuples that stay live for the whole kernel; the register allocator then spilled them to VGPR lanes
@@ -1335,7 +1340,9 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, fn);
     if (e != hipSuccess) return e;
-    if (variant != 1 && fa.localSizeBytes != 0) return hipErrorInvalidConfiguration; // register spills: see pt_render_wave_kernel
+    // register spills: see pt_render_wave_kernel.  PT_ALLOW_SCRATCH=1 in the environment lifts the refusal for the experiment that
+    // investigates it (profiles/r02_spill_investigation.md); never set it in production
+    if (variant != 1 && fa.localSizeBytes != 0 && !(getenv("PT_ALLOW_SCRATCH") && getenv("PT_ALLOW_SCRATCH")[0] == '1')) return hipErrorInvalidConfiguration;
     *vgprs = fa.numRegs;
     int nb = 0;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, *block, *lds_bytes);
