@@ -26,13 +26,31 @@ def main():
         ents = scene_io.build_entities(procedural.dragon_standin(du, dv), mats)
         W, H, spp = 1920, 1080, int(opts.get("spp", 1024))
         cam = B.to_camera_data([4, 2.5, 0], [0, .75, 0], [0, 1, 0], 50, W, H)
+    elif which == "c3":
+        _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "mitsuba.json"))
+        ents = scene_io.build_entities(procedural.mitsuba_standin(), mats)
+        W, H, spp = 1024, 1024, int(opts.get("spp", 512))
+        cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    elif which == "c5":
+        _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "car.json"))
+        ents = scene_io.build_entities(procedural.car_standin(), mats)
+        W, H, spp = 1920, 1080, int(opts.get("spp", 4096))
+        cam = B.to_camera_data([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, W, H)
     else:
         sc = scene_io.load_scene_dir(os.path.join(ROOT, "assets"), "cornell-box")
         mats, ents = sc["materials"], sc["entities"]
         W, H, spp = 512, 512, int(opts.get("spp", 256))
         c = sc["camera"]
         cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
-    ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    if which == "c5":
+        gi = [n for n, _, _ in mats].index("Ground")
+        envmap = procedural.rgbe_to_ldr_rgba8(procedural.synthetic_sky_rgbe(2048, 1024))
+        ctx.upload_scene(ents, [m for _, m, _ in mats], textures=[scene_io.checker_texture(256, 256, 16)], mesh_textures=[0 if mid == gi else -1 for _, mid in ents],
+                         env=B.make_env(use_map=True, intensity=1.0, env_map=envmap))
+    elif which == "c3":
+        ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(use_auto=True, intensity=1.0))
+    else:
+        ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
     if "shard_rank" in opts:
         ctx.set_pixel_shard(int(opts["shard_rank"]), int(opts.get("shard_world", 8)), int(opts.get("shard_tile", 16)))
     for k, v in opts.items():

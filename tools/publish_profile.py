@@ -27,8 +27,12 @@ pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
 pmc["command"] = "rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (tools/profile_round.sh)"
 json.dump(pmc, open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
 d = pmc["derived"]
+sys.path.insert(0, root)
+import bench as benchmod  # kernel_fingerprint(): bench.py quotes the PMC traffic only for the kernel sources it was measured on
+
+rnd = int(name[1:3]) if name[:1] == "r" and name[1:3].isdigit() else 0
 traffic = {
-    "round": 1, "kernel": "pt_render_wave_kernel<false>, main launch (2nd of 2 per frame)",
+    "round": rnd, "kernel_fingerprint": benchmod.kernel_fingerprint(), "kernel": "pt_render_wave_kernel<false>, main launch (2nd of 2 per frame)",
     "workload": "C4 dragon stand-in 1920x1080x1024spp depth 16, 1 GPU",
     "command": pmc["command"] + "; FETCH_SIZE and WRITE_SIZE in separate passes",
     "FETCH_SIZE_KB": pmc["counters_per_main_launch"]["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["counters_per_main_launch"]["WRITE_SIZE"],
@@ -37,5 +41,5 @@ traffic = {
     "traffic_bytes_per_launch": int(d["fetch_bytes"] + d["write_bytes"]), "l2_hit_rate": d["l2_hit_rate"],
     "kernel_ms": sum(pmc["main_launch_ms"]) / len(pmc["main_launch_ms"]),
 }
-json.dump(traffic, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, "r%02d_traffic.json" % rnd), "w"), indent=1)
 print(json.dumps({"value": bench["value"], "ms_per_step": bench["ms_per_step"], "roofline": bench["roofline"]["achieved"], "traffic": traffic["traffic_bytes_per_launch"]}))
