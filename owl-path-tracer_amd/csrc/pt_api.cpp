@@ -21,6 +21,9 @@ extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int 
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu);
 extern "C" int pt_debug_block(void);
+extern "C" size_t pt_lbvh_workspace_bytes(int n);
+extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_size, void* d_workspace, size_t workspace_bytes, PtNode* d_nodes, uint32_t* d_order,
+                                           int32_t* h_root, int32_t* h_n_nodes, int32_t* h_height, int32_t* h_max_leaf, float* h_pad, hipStream_t stream);
 
 namespace {
 std::string g_create_error;
@@ -273,6 +276,10 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
     else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
     else if (k == "adaptive") c->tune[5] = value ? 1 : 2;
+    else if (k == "bvh_builder") {
+        if (value != 0 && value != 1) return fail(c, PT_E_INVALID, "bvh_builder must be 0 (host binned SAH) or 1 (device LBVH)");
+        c->bvh_builder = (int)value;
+    }
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
     else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '7') c->tune[k[4] - '0'] = (int)value;
@@ -332,7 +339,48 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
 
     // ---- BVH (replaces owlGroupBuildAccel, application.cpp:135-139) ----
     auto t0 = std::chrono::steady_clock::now();
-    pt_bvh_build(pos.data(), (int32_t)n_tris, c->leaf_size, c->max_bvh_depth, &c->bvh);
+    const int leaf_sz = std::max(1, std::min(7, c->leaf_size));
+    if (c->bvh_builder == 1 && !c->host_only && n_tris > (size_t)leaf_sz) {
+        // device LBVH (pt_lbvh.hip): positions up, nodes + sorted order down - the host keeps its copy for the validation hooks
+        // and for the shading records, which follow the triangles into leaf order below
+        const int n = (int)n_tris;
+        DevBuf d_pos, d_ws, d_order;
+        int rc;
+        auto cleanup = [&]() { release(d_pos); release(d_ws); release(d_order); };
+        if ((rc = upload(c, d_pos, pos.data(), pos.size() * sizeof(float))) || (rc = ensure(c, d_ws, pt_lbvh_workspace_bytes(n))) ||
+            (rc = ensure(c, d_order, (size_t)n * 4)) || (rc = ensure(c, c->d_nodes, (size_t)(n - 1) * sizeof(PtNode)))) {
+            cleanup();
+            return rc;
+        }
+        int32_t root = -1, n_nodes = 0, height = 0, max_leaf = 0;
+        float pad = 0.0f;
+        hipError_t e = pt_lbvh_build_device((const float*)d_pos.p, n, leaf_sz, d_ws.p, d_ws.cap, (PtNode*)c->d_nodes.p, (uint32_t*)d_order.p, &root, &n_nodes,
+                                            &height, &max_leaf, &pad, c->stream);
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(c, PT_E_HIP, "device BVH build failed: %s", hipGetErrorString(e));
+        }
+        c->bvh.nodes.resize((size_t)n_nodes);
+        std::vector<uint32_t> order((size_t)n);
+        hipError_t e1 = hipMemcpy(c->bvh.nodes.data(), c->d_nodes.p, (size_t)n_nodes * sizeof(PtNode), hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(order.data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+        cleanup();
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, PT_E_HIP, "device BVH read-back failed");
+        c->bvh.root = root;
+        c->bvh.depth = height;
+        c->bvh.max_leaf = max_leaf;
+        c->bvh.pad = pad;
+        c->bvh.tris.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            PtTri& t = c->bvh.tris[(size_t)i];
+            std::memcpy(t.p0, &pos[(size_t)order[(size_t)i] * 9], 36);
+            t.id = (int32_t)order[(size_t)i];
+            t.material = -1;
+            t.pad = 0;
+        }
+    } else {
+        pt_bvh_build(pos.data(), (int32_t)n_tris, c->leaf_size, c->max_bvh_depth, &c->bvh);
+    }
     auto t1 = std::chrono::steady_clock::now();
     c->stats.bvh_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     c->stats.bvh_nodes = c->bvh.nodes.size();

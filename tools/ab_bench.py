@@ -8,7 +8,7 @@ import ptamd
 ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
 
-PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align")  # builder / layout options: before upload_scene
+PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align", "bvh_builder")  # builder / layout options: before upload_scene
 NOT_OPTIONS = ("spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
 
 
@@ -99,6 +99,6 @@ def main():
         print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
                       "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
-                      "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"]}))
+                      "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": round(st["bvh_build_ms"], 2)}))
 
 main()
