@@ -11,6 +11,7 @@
 // librccl.so.1 is resolved at the first communicator call (dlopen): a single-GPU user never maps the 570 MB library, and a
 // process that already holds an RCCL (PyTorch-ROCm bundles one under the same SONAME) keeps exactly one copy.
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstring>
@@ -20,24 +21,19 @@
 
 namespace {
 
-// the subset of <rccl/rccl.h> this file calls (ABI of RCCL 2.x / ROCm 7)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclUint32 = 3, ncclFloat32 = 7 }; // ncclDataType_t
-enum { ncclSum = 0 };                     // ncclRedOp_t
+// Types and prototypes come from the RCCL header; the functions themselves are resolved with dlsym (see the file comment).
 static_assert(PT_COMM_ID_BYTES == sizeof(ncclUniqueId), "PT_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 
 struct Rccl {
     void* handle = nullptr;
-    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*Reduce)(const void*, void*, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
 
@@ -75,7 +71,7 @@ int need_rccl(pt_ctx* c)
 
 #define RCCL_TRY(c, call)                                                                                            \
     do {                                                                                                             \
-        int r__ = (call);                                                                                            \
+        ncclResult_t r__ = (call);                                                                                            \
         if (r__ != ncclSuccess) return pti::fail(c, PT_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r__));   \
     } while (0)
 
@@ -176,7 +172,7 @@ pt_group* pt_group_create(const int32_t* devices, int32_t n)
     if (n > 1) {
         if (need_rccl(nullptr)) { pt_group_destroy(g); return nullptr; }
         std::vector<ncclComm_t> comms((size_t)n, nullptr);
-        int r = g_rccl.CommInitAll(comms.data(), n, devs.data());
+        ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devs.data());
         if (r != ncclSuccess) {
             pti::fail(nullptr, PT_E_HIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
             pt_group_destroy(g);
@@ -279,7 +275,7 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t W, int32_t H, int
         RCCL_TRY(c0, g_rccl.GroupStart());
         for (int i = 0; i < n; ++i) {
             pt_ctx* c = g->ctx[(size_t)i];
-            int r = g_rccl.Reduce(g->d_rgb[(size_t)i], g->d_rgb[(size_t)i], npx * 3, ncclFloat32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
+            ncclResult_t r = g_rccl.Reduce(g->d_rgb[(size_t)i], g->d_rgb[(size_t)i], npx * 3, ncclFloat32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
             if (r == ncclSuccess && out_rgba8)
                 r = g_rccl.Reduce(g->d_rgba8[(size_t)i], g->d_rgba8[(size_t)i], npx, ncclUint32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
             if (r != ncclSuccess) {
