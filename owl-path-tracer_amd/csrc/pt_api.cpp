@@ -244,7 +244,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
-        DevBuf* bufs[] = {&c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
+        DevBuf* bufs[] = {&c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
                           &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
@@ -280,6 +280,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value != 0 && value != 1) return fail(c, PT_E_INVALID, "bvh_builder must be 0 (host binned SAH) or 1 (device LBVH)");
         c->bvh_builder = (int)value;
     }
+    else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
     else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '7') c->tune[k[4] - '0'] = (int)value;
@@ -389,6 +390,8 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     if (c->bvh.depth > PT_MAX_STACK) return fail(c, PT_E_LIMIT, "BVH depth %d exceeds %d", c->bvh.depth, PT_MAX_STACK);
     pt_bvh_layout(&c->bvh, c->node_pairs, c->leaf_align);
     c->stats.bvh_nodes = c->bvh.nodes.size();
+    pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
+    if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
     { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
         const size_t n_slots = c->bvh.tris.size();
         std::vector<PtShade> by_leaf(n_slots);
@@ -419,6 +422,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
 
     int rc;
     if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
+    if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
     if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
     if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
     for (void* p : c->d_textures) (void)hipFree(p);
@@ -501,6 +505,11 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
     PtKernelParams P;
     fill_params(c, P);
+    if (c->kernel == 2 && c->quad && !c->nodes4.empty()) { // the wavefront kernel walks the quad nodes: own root and stack bound
+        P.nodes4 = (const PtNode4*)c->d_nodes4.p;
+        P.root = c->root4;
+        P.stack_entries = 3 * c->depth4 + 1;
+    }
 
     // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.

@@ -215,6 +215,53 @@ static void layout_align_leaves(PtBvh* b, int align)
     b->tris.swap(out);
 }
 
+void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4, int* depth4)
+{
+    out->clear();
+    *root4 = b.root;
+    *depth4 = 0;
+    if (b.root < 0) return; // empty scene or a leaf as root: no quad nodes
+    struct Item { int32_t node2; int32_t idx4; int depth; };
+    std::vector<Item> todo;
+    out->emplace_back();
+    todo.push_back({b.root, 0, 1});
+    *root4 = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        *depth4 = std::max(*depth4, it.depth);
+        const PtNode& nd = b.nodes[(size_t)it.node2];
+        PtNode4 q;
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 4; ++k) q.lo[a][k] = q.hi[a][k] = INFINITY; // never hit (empty slot)
+        for (int k = 0; k < 4; ++k) { q.child[k] = -1; q.pad[k] = 0; }
+        for (int side = 0; side < 2; ++side) {
+            const int32_t c = side ? nd.right : nd.left;
+            if (c >= 0) { // internal child: its two children take the slots of this side
+                const PtNode& cn = b.nodes[(size_t)c];
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int slot = side * 2 + s2;
+                    const int32_t gc = s2 ? cn.right : cn.left;
+                    for (int a = 0; a < 3; ++a) { q.lo[a][slot] = cn.lo[a][s2]; q.hi[a][slot] = cn.hi[a][s2]; }
+                    if (gc >= 0) {
+                        const int32_t idx = (int32_t)out->size();
+                        out->emplace_back();
+                        q.child[slot] = idx;
+                        todo.push_back({gc, idx, it.depth + 1});
+                    } else {
+                        q.child[slot] = gc;
+                    }
+                }
+            } else if (c < -1) { // leaf child: keeps its own box
+                const int slot = side * 2;
+                for (int a = 0; a < 3; ++a) { q.lo[a][slot] = nd.lo[a][side]; q.hi[a][slot] = nd.hi[a][side]; }
+                q.child[slot] = c;
+            }
+        }
+        (*out)[(size_t)it.idx4] = q;
+    }
+}
+
 void pt_bvh_layout(PtBvh* b, int sibling_pairs, int leaf_align)
 {
     if (sibling_pairs) layout_sibling_pairs(b);

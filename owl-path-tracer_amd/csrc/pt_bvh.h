@@ -24,6 +24,10 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
 // After it tris.size() may exceed the triangle count.
 void pt_bvh_layout(PtBvh* bvh, int sibling_pairs, int leaf_align);
 
+// Two-level collapse of the binary tree into quad nodes (PtNode4, pt_types.h).  root4 = 0 when the root is an internal node (else the
+// binary root reference: leaf code or -1), depth4 = deepest chain of quad nodes (the traversal stack needs 3 * depth4 entries).
+void pt_bvh_collapse4(const PtBvh& bvh, std::vector<PtNode4>* out, int32_t* root4, int* depth4);
+
 // Host mirror of the kernel's traversal over the product BVH (validation only, never on the render path).
 bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u,
                              float* v, int32_t* prim);

@@ -54,6 +54,9 @@ using namespace ptd;
 #ifndef PT_NODE_REPS
 #define PT_NODE_REPS 2 // consecutive node steps per scheduler iteration in the common (LDS-stack-only) instance
 #endif
+#ifndef PT_QUAD_REPS
+#define PT_QUAD_REPS 1 // quad-node steps per burst (a quad step is two binary levels and up to three pushes)
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -201,6 +204,72 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
         ++sp;
     }
     if (hl || hr) {
+        cur = nearc;
+    } else if (sp > 0) {
+        --sp;
+        cur = (int)stack_pop<STRIDE, LDS_ENTRIES>(stack, ovf, sp);
+    } else {
+        cur = PT_DONE;
+    }
+}
+
+// Quad-node step (PtNode4, pt_types.h): the four grandchild boxes of a binary node in one 128-byte record - one cache line and
+// one memory round trip per TWO levels of the binary tree.  Slab test as in node_step, two packed pairs; the lane continues with
+// the nearest hit child and pushes the other hit children (in slot order; any visiting order gives the same closest hit).
+template <int STRIDE, int LDS_ENTRIES>
+__device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest, int& cur, int& sp)
+{
+    const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4);
+    const f32x4 lx = ldg4(nodes4, nb), ly = ldg4(nodes4, nb + 16), lz = ldg4(nodes4, nb + 32);
+    const f32x4 hx = ldg4(nodes4, nb + 48), hy = ldg4(nodes4, nb + 64), hz = ldg4(nodes4, nb + 80), cf = ldg4(nodes4, nb + 96);
+    const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const f32x2 pad = {1.0000004f, 1.0000004f};
+    float tn[4];
+    bool hit[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { // slots {0, 1} and {2, 3}
+        const f32x2 lox = p ? (f32x2){lx.z, lx.w} : (f32x2){lx.x, lx.y}, loy = p ? (f32x2){ly.z, ly.w} : (f32x2){ly.x, ly.y};
+        const f32x2 loz = p ? (f32x2){lz.z, lz.w} : (f32x2){lz.x, lz.y}, hix = p ? (f32x2){hx.z, hx.w} : (f32x2){hx.x, hx.y};
+        const f32x2 hiy = p ? (f32x2){hy.z, hy.w} : (f32x2){hy.x, hy.y}, hiz = p ? (f32x2){hz.z, hz.w} : (f32x2){hz.x, hz.y};
+        const f32x2 t0x = (lox - ox) * ix, t1x = (hix - ox) * ix;
+        const f32x2 t0y = (loy - oy) * iy, t1y = (hiy - oy) * iy;
+        const f32x2 t0z = (loz - oz) * iz, t1z = (hiz - oz) * iz;
+        const float ta = fmax_hw(fmax_hw(fmin_hw(t0x.x, t1x.x), fmin_hw(t0y.x, t1y.x)), fmax_hw(fmin_hw(t0z.x, t1z.x), kTMin));
+        const float tb = fmax_hw(fmax_hw(fmin_hw(t0x.y, t1x.y), fmin_hw(t0y.y, t1y.y)), fmax_hw(fmin_hw(t0z.y, t1z.y), kTMin));
+        f32x2 tf = {fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmin_hw(fmax_hw(t0z.x, t1z.x), tbest)),
+                    fmin_hw(fmin_hw(fmax_hw(t0x.y, t1x.y), fmax_hw(t0y.y, t1y.y)), fmin_hw(fmax_hw(t0z.y, t1z.y), tbest))};
+        tf = tf * pad;
+        tn[2 * p] = ta; tn[2 * p + 1] = tb;
+        hit[2 * p] = ta <= tf.x; hit[2 * p + 1] = tb <= tf.y;
+    }
+    const int r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
+    const float far_key = kTMax * 2.0f; // beyond every valid entry distance
+    const float k0 = hit[0] ? tn[0] : far_key, k1 = hit[1] ? tn[1] : far_key, k2 = hit[2] ? tn[2] : far_key, k3 = hit[3] ? tn[3] : far_key;
+    const bool b01 = k1 < k0, b23 = k3 < k2;
+    const float m01 = b01 ? k1 : k0, m23 = b23 ? k3 : k2;
+    const int r01 = b01 ? r1 : r0, r23 = b23 ? r3 : r2;
+    const bool in_b = m23 < m01; // the nearest hit is in slot pair {2, 3}
+    const int nearc = in_b ? r23 : r01;
+    const bool any = hit[0] || hit[1] || hit[2] || hit[3];
+    // push order: the two slots of the OTHER pair first, the nearest's sibling last (popped first): siblings share a parent box, so
+    // the sibling is usually the next nearest.  Three pushes at most.
+    const int x1 = in_b ? r0 : r2, x2 = in_b ? r1 : r3;
+    const bool h1 = in_b ? hit[0] : hit[2], h2 = in_b ? hit[1] : hit[3];
+    const bool first_of_pair = in_b ? !b23 : !b01; // the nearest is the first slot of its pair
+    const int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
+    const bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
+    if (LDS_ENTRIES == 0x7fffffff) {
+        // common instance (the caller made sure sp + 3 stays inside the LDS part): store above the top whether or not the entry is
+        // pushed - the slot is free either way - and advance sp by the predicate; no branches
+        stack[sp * STRIDE] = (uint32_t)x1; sp += h1 ? 1 : 0;
+        stack[sp * STRIDE] = (uint32_t)x2; sp += h2 ? 1 : 0;
+        stack[sp * STRIDE] = (uint32_t)x3; sp += h3 ? 1 : 0;
+    } else {
+        if (h1) { stack_push<STRIDE, LDS_ENTRIES>(stack, ovf, sp, (uint32_t)x1); ++sp; }
+        if (h2) { stack_push<STRIDE, LDS_ENTRIES>(stack, ovf, sp, (uint32_t)x2); ++sp; }
+        if (h3) { stack_push<STRIDE, LDS_ENTRIES>(stack, ovf, sp, (uint32_t)x3); ++sp; }
+    }
+    if (any) {
         cur = nearc;
     } else if (sp > 0) {
         --sp;
@@ -861,6 +930,7 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
     w.hitq = w.rayq + ns;
     w.missq = w.hitq + ns;
     const PtNode* __restrict__ nodes = P.nodes;
+    const PtNode4* __restrict__ nodes4 = P.nodes4;
     const PtTri* __restrict__ tris = P.tris;
 
 #define LF(f, s) lray[(f) * ns + (s)]
@@ -1025,20 +1095,26 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
                     // The scheduler round around a step (three ballots, retire test, majority vote, loop-carried copies) costs about as
                     // much as the step: node steps come in bursts of PT_NODE_REPS, repeated while >= PT_NODE_KEEP lanes still want one
                     // (1 x 1 -> 2 x up to 3: C4 626 -> 599 ms, its 1/8 shard 480 -> 435 ms, C2 98 -> 91 ms).
-                    if (__ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) == 0ull) {
+                    // every push of a burst must stay inside the LDS part of the stack for the common instance: one push per step when
+                    // walking PtNode[], up to three per quad-node step
+                    const int n_reps = nodes4 ? PT_QUAD_REPS : PT_NODE_REPS;
+                    const int sp_lim = nodes4 ? PT_LDS_STACK - 3 * PT_QUAD_REPS : PT_LDS_STACK - PT_NODE_REPS;
+                    if (__ballot(sp > sp_lim) == 0ull) {
 #if PT_NODE_KEEP > 0
                       // a sparse wave (adapt): the bursts go on while at least half of the lanes that started them want another step, up to twice as many
                       const int n_node0 = popc64(m_node);
                       const int keep = w.adapt && n_node0 < 2 * PT_NODE_KEEP ? (n_node0 + 1) / 2 : PT_NODE_KEEP;
-                      const int max_bursts = w.adapt && n_node0 < PT_NODE_KEEP ? 2 * PT_NODE_BURSTS : PT_NODE_BURSTS;
+                      const int max_bursts = (w.adapt && n_node0 < PT_NODE_KEEP ? 2 * PT_NODE_BURSTS : PT_NODE_BURSTS) * (PT_NODE_REPS / (nodes4 ? PT_QUAD_REPS : PT_NODE_REPS));
                       for (int burst = 0; burst < max_bursts; ++burst) {
-                        if (burst > 0 && (popc64(__ballot(cur >= 0)) < keep || __ballot(sp >= PT_LDS_STACK - (PT_NODE_REPS - 1)) != 0ull)) break;
+                        if (burst > 0 && (popc64(__ballot(cur >= 0)) < keep || __ballot(sp > sp_lim) != 0ull)) break;
 #endif
 #pragma unroll
                         for (int rep = 0; rep < PT_NODE_REPS; ++rep) {
+                            if (rep >= n_reps) break;
                             if (cur >= 0) {
-                                if (COUNT) ++cn.nodes;
-                                node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                                if (COUNT) cn.nodes += nodes4 ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
+                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff>(nodes4, stack, ovf, o, inv, h.t, cur, sp);
+                                else node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
                                 if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
                                     pend = cur;
                                     if (sp > 0) {
@@ -1054,8 +1130,9 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
                       }
 #endif
                     } else if (cur >= 0) {
-                        if (COUNT) ++cn.nodes;
-                        node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                        if (COUNT) cn.nodes += nodes4 ? 2 : 1;
+                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp);
+                        else node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
                         if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;
                             if (sp > 0) {

@@ -15,6 +15,21 @@ struct PtNode {
 };
 static_assert(sizeof(PtNode) == 64, "PtNode must be 64 bytes");
 
+// Two binary levels per record ("quad node", wavefront kernel): the boxes of the four GRANDchildren of binary node i, so that one
+// 128-byte record - one cache line, one memory round trip - takes a ray two levels down the binary tree.  Slot 2 * side + s holds
+// child s of the left (side 0) / right (side 1) child of node i; where a child of node i is itself a leaf it occupies slot
+// 2 * side with its own box and slot 2 * side + 1 is empty.  Built by pt_bvh_collapse4 from the PtNode[] tree (same boxes, same
+// leaves, same topology - the intermediate level's boxes are simply not stored); planes are laid out per axis for the packed-f32
+// slab test: lo[axis] = {slot 0, 1, 2, 3}.
+// child >= 0: quad node index; < -1: leaf code as in PtNode; -1: empty slot (its box is {+inf, +inf}: never hit).
+struct PtNode4 {
+    float lo[3][4];
+    float hi[3][4];
+    int32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(PtNode4) == 128, "PtNode4 must be 128 bytes");
+
 // One triangle in LEAF order: the three vertices (the reference's vertex_buffer values, fetched through
 // index_buffer: device.cu:42-61) + its global id (entity order, then face order).  48 bytes = 3 x dwordx4.
 struct PtTri {
@@ -97,5 +112,6 @@ struct PtKernelParams {
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];
+    const PtNode4* nodes4;     // wavefront kernel: quad nodes (null: walk PtNode[] one level per step); root / stack_entries then refer to them
     int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
 };
