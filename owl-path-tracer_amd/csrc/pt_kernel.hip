@@ -8,10 +8,14 @@
 //    (a slot = one pixel in flight with its RNG stream, accumulators and current ray) plus three slot queues:
 //    rays waiting for traversal, hits and misses waiting for shading.  The wave alternates between
 //      * a TRAVERSAL phase: every lane walks one ray (speculatively: one stashed leaf per lane); each step the wave
-//        executes either one BVH-node step or one whole-leaf triangle step, whichever more lanes are waiting for
-//        (ballot majority); finished lanes retire in batches into the hit / miss queue and pull the next ray;
+//        executes either a burst of BVH-node steps or one whole-leaf triangle step, whichever more lanes are waiting for
+//        (ballot majority); finished lanes retire in batches into the hit / miss queue and pull the next ray.  A node step
+//        reads the binary tree TWO levels at a time from 128-byte quad-node records (node4_step; option quad = 0: one level
+//        per step from the 64-byte records, node_step); a leaf step requests all triangles of the leaf before the first test;
 //      * a SHADING pass over up to 64 queued hits (emitter / BSDF sample / Russian roulette) or misses (environment,
 //        sample accumulation, next camera ray / next work item), which emits the continuation rays into the ray queue.
+//    The batch sizes follow the number of pixels the wave still runs ("adaptive"), so that a sparse wave does not wait for
+//    its slowest ray before it shades anything.
 //    Lanes are workers, not pixel owners: a ray's lane is unrelated to the lane that shades its hit.  The per-pixel
 //    sample order -- hence the reference's per-pixel RNG stream (device.cu:226-243) -- is preserved because a slot
 //    has at most one ray in flight.  Work items are (pixel, sample chunk) tickets; the host orders the pixel queue by a
@@ -253,8 +257,12 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     const bool any = hit[0] || hit[1] || hit[2] || hit[3];
     // push order: the two slots of the OTHER pair first, the nearest's sibling last (popped first): siblings share a parent box, so
     // the sibling is usually the next nearest.  Three pushes at most.
-    const int x1 = in_b ? r0 : r2, x2 = in_b ? r1 : r3;
-    const bool h1 = in_b ? hit[0] : hit[2], h2 = in_b ? hit[1] : hit[3];
+    // (of the other pair, the farther slot first)
+    const bool swap_o = in_b ? b01 : b23; // the other pair's second slot is the nearer one: push it second
+    const int oa = in_b ? r0 : r2, ob = in_b ? r1 : r3;
+    const bool ha = in_b ? hit[0] : hit[2], hb = in_b ? hit[1] : hit[3];
+    const int x1 = swap_o ? oa : ob, x2 = swap_o ? ob : oa;
+    const bool h1 = swap_o ? ha : hb, h2 = swap_o ? hb : ha;
     const bool first_of_pair = in_b ? !b23 : !b01; // the nearest is the first slot of its pair
     const int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
     const bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
