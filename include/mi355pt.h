@@ -189,6 +189,11 @@ int pt_debug_closest_hit_host(pt_ctx* ctx, const float org[3], const float dir[3
  * lets the parity tests compare them bit-for-bit with the oracle.  in/out are host arrays. */
 int pt_debug_eval(pt_ctx* ctx, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n);
 
+/* Structure of the quad nodes the wavefront kernel walks (host side, no GPU needed): out = {quad nodes, depth, leaf slots,
+ * triangles in leaf slots, empty slots, internal slots, binary nodes, binary leaf references}.  Every leaf of the binary tree
+ * must appear in exactly one quad slot; an empty slot must carry the never-hit box. */
+int pt_debug_quad_info(pt_ctx* ctx, int64_t out[8]);
+
 /* The pixel queue of the last pt_render* call with the cost-ordered schedule: queue_ids[i] = pixel id (x + width * y) of
  * entry i of the cost-ordered queue, input_ids[i] / cost[i] = entry i of the shard's input queue and the rays its first
  * prepass_spp samples traced (saturating at 255).  Any pointer may be NULL.  Returns the number of entries (0: the last

@@ -818,6 +818,35 @@ int pt_debug_closest_hit_host(pt_ctx* c, const float org[3], const float dir[3],
     return pt_bvh_closest_hit_host(c->bvh, org, dir, tmin, tmax, t, u, v, prim) ? 1 : 0;
 }
 
+int pt_debug_quad_info(pt_ctx* c, int64_t out[8])
+{
+    if (!c || !out) return PT_E_INVALID;
+    if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "pt_debug_quad_info before pt_upload_scene");
+    // {quad nodes, depth, leaf slots, triangles in leaf slots, empty slots, internal slots, binary nodes, binary leaf references}
+    int64_t leaf_slots = 0, tris = 0, empty = 0, internal = 0, bin_leaves = 0;
+    for (const PtNode4& q : c->nodes4) {
+        for (int k = 0; k < 4; ++k) {
+            const int32_t r = q.child[k];
+            if (r >= 0) ++internal;
+            else if (r == -1) {
+                ++empty;
+                for (int a = 0; a < 3; ++a)
+                    if (!(q.lo[a][k] == INFINITY && q.hi[a][k] == INFINITY)) return fail(c, PT_E_LIMIT, "quad node: empty slot with a finite box");
+            } else {
+                ++leaf_slots;
+                tris += (int64_t)(~(uint32_t)r & 7u);
+            }
+        }
+    }
+    for (const PtNode& nd : c->bvh.nodes) {
+        if (nd.left < -1) ++bin_leaves;
+        if (nd.right < -1) ++bin_leaves;
+    }
+    out[0] = (int64_t)c->nodes4.size(); out[1] = c->depth4; out[2] = leaf_slots; out[3] = tris; out[4] = empty; out[5] = internal;
+    out[6] = (int64_t)c->bvh.nodes.size(); out[7] = bin_leaves;
+    return PT_OK;
+}
+
 int64_t pt_debug_read_queue(pt_ctx* c, uint32_t* queue_ids, uint32_t* input_ids, uint8_t* cost, int64_t cap)
 {
     if (!c) return PT_E_INVALID;

@@ -129,3 +129,20 @@ def test_shard_pixels_partition(W, H, tile, world):
     if W >= 8 and H >= 8:
         xs, ys = p % W, p // W
         assert xs.max() - xs.min() == 7 and ys.max() - ys.min() == 7
+
+
+@pytest.mark.parametrize("leaf", [1, 4, 7])
+def test_quad_nodes_cover_the_binary_tree(cornell, leaf):
+    """The two-level collapse the wavefront kernel walks (PtNode4): every leaf reference of the binary tree sits in exactly one quad
+    slot, all triangles are covered once, internal slots chain to exactly the other quad nodes, empty slots carry the never-hit box."""
+    ctx = B.Context(-1)
+    ctx.set_option("leaf_size", leaf)
+    ctx.upload_scene(cornell["entities"], [m for _, m, _ in cornell["materials"]])
+    q = ctx.quad_info()
+    n_tris = cornell["flat"]["positions"].reshape(-1, 9).shape[0]
+    assert q["triangles"] == n_tris
+    assert q["leaf_slots"] == q["binary_leaf_refs"]
+    assert q["internal_slots"] == q["quad_nodes"] - 1  # every quad node but the root is referenced once
+    assert q["leaf_slots"] + q["internal_slots"] + q["empty_slots"] == 4 * q["quad_nodes"]
+    assert 0 < q["quad_nodes"] < q["binary_nodes"] and 0 < q["depth"] <= (ctx.stats()["bvh_depth"] + 1) // 2 + 1
+    ctx.close()
