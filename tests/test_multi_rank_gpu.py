@@ -1,0 +1,77 @@
+"""N processes, one GPU each, through the library's own communicator (pt_comm_get_unique_id / pt_comm_init_rank / pt_render): the frame
+rank 0 receives must equal the single-GPU frame bit for bit.  Needs >= 2 GPUs: skipped on the one-GPU boxes of this pool (there the
+same entry points run with world size 1 in tests/test_gpu_parity.py::test_library_communicator_single_rank and through
+`pt_main --gpus 1`); no torch.distributed involved - the 128-byte id travels through a file, as any launcher could do it."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import os, sys, time, numpy as np
+sys.path.insert(0, %(root)r)
+import ptamd; ptamd.load()
+from owl_path_tracer_amd.pyhost import binding as B, scene_io
+rank, world, tmp = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+sc = scene_io.load_scene_dir(os.path.join(%(root)r, "assets"), "cornell-box")
+ctx = B.Context(rank)
+ctx.upload_scene(sc["entities"], [m for _, m, _ in sc["materials"]], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+idf = os.path.join(tmp, "comm_id.bin")
+if rank == 0:
+    uid = B.comm_unique_id()
+    with open(idf + ".tmp", "wb") as f: f.write(uid)
+    os.replace(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        if time.time() - t0 > 120: raise SystemExit("no communicator id from rank 0")
+        time.sleep(0.05)
+    uid = open(idf, "rb").read()
+ctx.comm_init_rank(uid, rank, world)
+W, H = 320, 200
+c = sc["camera"]
+cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+fr = B.PinnedFrame(W, H, want_rgba8=True) if rank == 0 else None
+for _ in range(2):  # twice: the communicator is reused
+    ctx.render_into(cam, W, H, 48, 16, fr.rgb if fr else None, fr.rgba8 if fr else None)
+if rank == 0:
+    np.save(os.path.join(tmp, "rgb.npy"), np.array(fr.rgb)); np.save(os.path.join(tmp, "rgba8.npy"), np.array(fr.rgba8))
+ctx.comm_destroy(); ctx.close()
+'''
+
+
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_library_reduce_across_processes(tmp_path, world):
+    if _device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT), str(r), str(world), str(tmp_path)], env=env) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.wait(timeout=max(1.0, 600 - (time.time() - t0)))
+    assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
+    sys.path.insert(0, ROOT)
+    from owl_path_tracer_amd.pyhost import binding as B, scene_io
+
+    sc = scene_io.load_scene_dir(os.path.join(ROOT, "assets"), "cornell-box")
+    ctx = B.Context(0)
+    ctx.upload_scene(sc["entities"], [m for _, m, _ in sc["materials"]], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    c = sc["camera"]
+    cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], 320, 200)
+    want, want8 = ctx.render(cam, 320, 200, 48, 16, want_rgba8=True)
+    ctx.close()
+    np.testing.assert_array_equal(np.load(tmp_path / "rgb.npy").view(np.uint32), want.view(np.uint32))
+    np.testing.assert_array_equal(np.load(tmp_path / "rgba8.npy"), want8)
