@@ -23,7 +23,9 @@
 //
 //  pt_render_kernel (option kernel=1): the simple persistent lane-per-pixel form kept for A/B measurements.
 //
-// The traversal stack is stack[level][lane] in LDS: bank = lane % 32 whatever the level, conflict-free.
+// The traversal stack is stack[level][lane] in LDS: bank = lane % 32 whatever the level, so the stack itself is conflict-free (the LDS
+// bank conflicts rocprof reports - a third of the LDS cycles, at ~6 % LDS utilisation - come from the slot-indexed state arrays,
+// lray / lstate[field * ns + slot], where lanes hold arbitrary slots).
 #include <cstdlib>
 
 #include "pt_device.h"
@@ -160,7 +162,7 @@ __device__ __forceinline__ void leaf_test(const PtTri* __restrict__ tris, int fi
 
 // One BVH-node step for a lane: test both children, descend into the nearer hit child, push the other.
 // Stack entry i lives in LDS (stack[i * STRIDE]) for i < LDS_ENTRIES, else in the lane's HBM overflow column
-// (ovf[(i - LDS_ENTRIES) * STRIDE]): on C4 0.006 % of the pushes go deeper than 12 (profiles/r01_sweeps.md), so a 12-entry LDS
+// (ovf[(i - LDS_ENTRIES) * STRIDE]): on C4 0.006 % of the binary walk's pushes go deeper than 12 (census of the instrumented build: profiles/r01_summary.md), so a 12-entry LDS
 // stack halves the LDS a wave needs for BVHs of any depth.  LDS_ENTRIES = 0x7fffffff: everything in LDS.
 template <int STRIDE, int LDS_ENTRIES>
 __device__ __forceinline__ void stack_push(uint32_t* stack, uint32_t PT_AS1* ovf, int sp, uint32_t v)
