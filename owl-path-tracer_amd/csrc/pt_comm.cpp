@@ -128,7 +128,7 @@ int pt_comm_destroy(pt_ctx* c)
     }
     c->comm_rank = 0;
     c->comm_world = 1;
-    return PT_OK;
+    return pt_set_pixel_shard(c, 0, 1, c->tile > 0 ? c->tile : 16); // the context renders every pixel again
 }
 
 int pt_reduce_framebuffer(pt_ctx* c, void* d_rgb, void* d_rgba8, int64_t n_pixels, void* stream_v)
