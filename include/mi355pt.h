@@ -189,6 +189,10 @@ int pt_debug_closest_hit_host(pt_ctx* ctx, const float org[3], const float dir[3
  * lets the parity tests compare them bit-for-bit with the oracle.  in/out are host arrays. */
 int pt_debug_eval(pt_ctx* ctx, int32_t op, const float* in, int32_t in_stride, float* out, int32_t out_stride, int64_t n);
 
+/* What pt_group_upload_scene does for devices 1..n-1: the scene `src` holds (BVH built once) copied into `dst` and uploaded to
+ * dst's GPU.  Exposed so that a one-GPU box can test it with two contexts on the same device. */
+int pt_debug_clone_scene(pt_ctx* dst, const pt_ctx* src);
+
 /* Structure of the quad nodes the wavefront kernel walks (host side, no GPU needed): out = {quad nodes, depth, leaf slots,
  * triangles in leaf slots, empty slots, internal slots, binary nodes, binary leaf references}.  Every leaf of the binary tree
  * must appear in exactly one quad slot; an empty slot must carry the never-hit box. */

@@ -419,7 +419,18 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     copy_env(c, env ? env : &def);
     c->have_scene = true;
     if (c->host_only) return PT_OK;
+    return pti::upload_scene_to_device(c);
+}
 
+} // extern "C"
+
+namespace pti {
+
+// Host copies of the scene (BVH, quad nodes, triangles, shading records, textures, materials, environment) -> this context's GPU.
+int upload_scene_to_device(pt_ctx* c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n_textures = (int)c->textures.size();
     int rc;
     if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
     if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
@@ -444,6 +455,36 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
+
+// The scene of `src` (built once: BVH, leaf-order records, quad nodes) copied into `dst` and uploaded to dst's GPU: the replicas
+// of a multi-GPU group (pt_group_upload_scene) do not each rebuild the BVH on the host.
+int clone_scene(pt_ctx* dst, const pt_ctx* src)
+{
+    if (!src->have_scene) return fail(dst, PT_E_NO_SCENE, "clone_scene: the source context has no scene");
+    dst->bvh = src->bvh;
+    dst->nodes4 = src->nodes4;
+    dst->root4 = src->root4;
+    dst->depth4 = src->depth4;
+    dst->shade = src->shade;
+    dst->materials = src->materials;
+    dst->n_materials = src->n_materials;
+    dst->material_texture = src->material_texture;
+    dst->textures = src->textures;
+    dst->env = src->env;
+    dst->env_map = src->env_map;
+    dst->stats.bvh_build_ms = src->stats.bvh_build_ms;
+    dst->stats.bvh_nodes = src->stats.bvh_nodes;
+    dst->stats.bvh_depth = src->stats.bvh_depth;
+    dst->stats.n_triangles = src->stats.n_triangles;
+    dst->have_scene = true;
+    dst->queue_valid = false;
+    if (dst->host_only) return PT_OK;
+    return upload_scene_to_device(dst);
+}
+
+} // namespace pti
+
+extern "C" {
 
 int pt_set_materials(pt_ctx* c, const float* materials, int32_t n_materials)
 {
@@ -816,6 +857,12 @@ int pt_debug_closest_hit_host(pt_ctx* c, const float org[3], const float dir[3],
 {
     if (!c || !c->have_scene) return PT_E_NO_SCENE;
     return pt_bvh_closest_hit_host(c->bvh, org, dir, tmin, tmax, t, u, v, prim) ? 1 : 0;
+}
+
+int pt_debug_clone_scene(pt_ctx* dst, const pt_ctx* src)
+{
+    if (!dst || !src || dst == src) return PT_E_INVALID;
+    return pti::clone_scene(dst, src);
 }
 
 int pt_debug_quad_info(pt_ctx* c, int64_t out[8])

@@ -222,7 +222,14 @@ int pt_group_upload_scene(pt_group* g, const pt_mesh* meshes, int32_t n_meshes, 
                           int32_t n_textures, const int32_t* material_texture, const pt_env* env)
 {
     if (!g) return PT_E_INVALID;
-    GROUP_EACH(g, pt_upload_scene(c_, meshes, n_meshes, materials, n_materials, textures, n_textures, material_texture, env)); // full replica per GPU
+    // the BVH is built once (device 0's context), every other device gets a copy: full replica per GPU
+    pt_ctx* c0 = g->ctx[0];
+    int rc = pt_upload_scene(c0, meshes, n_meshes, materials, n_materials, textures, n_textures, material_texture, env);
+    if (rc) { g->err = pt_last_error(c0); return rc; }
+    for (size_t i = 1; i < g->ctx.size(); ++i) {
+        rc = pti::clone_scene(g->ctx[i], c0);
+        if (rc) { g->err = pt_last_error(g->ctx[i]); return rc; }
+    }
     return PT_OK;
 }
 

@@ -74,6 +74,8 @@ namespace pti {
 int fail(pt_ctx* c, int code, const char* fmt, ...);
 int ensure(pt_ctx* c, DevBuf& b, size_t bytes);
 int check_watchdog(pt_ctx* c);
+int upload_scene_to_device(pt_ctx* c);
+int clone_scene(pt_ctx* dst, const pt_ctx* src);
 } // namespace pti
 
 #define HIP_TRY(c, call)                                                                                   \

@@ -64,7 +64,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upl
            "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_framebuffer", "pt_host_alloc", "pt_host_free",
            "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_ctx", "pt_group_last_error", "pt_group_upload_scene",
-           "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info"]
+           "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info", "pt_debug_clone_scene"]
 PT_COMM_ID_BYTES = 128
 
 _lib = None
@@ -128,6 +128,7 @@ def lib():
     L.pt_group_set_materials.argtypes = [C.c_void_p, fp, C.c_int32]
     L.pt_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.pt_debug_quad_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.pt_debug_clone_scene.argtypes = [C.c_void_p, C.c_void_p]
     L.pt_group_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
@@ -315,6 +316,9 @@ class Context:
         rc = self._check(lib().pt_debug_closest_hit_host(self._h, _vec3(org), _vec3(direction), tmin, tmax, C.byref(t), C.byref(u), C.byref(v),
                                                          C.byref(p)), "pt_debug_closest_hit_host")
         return bool(rc), float(t.value), float(u.value), float(v.value), int(p.value)
+
+    def clone_scene_from(self, other):
+        self._check(lib().pt_debug_clone_scene(self._h, other._h), "pt_debug_clone_scene")
 
     def quad_info(self):
         a = (C.c_int64 * 8)()

@@ -631,3 +631,28 @@ def test_device_lbvh_builder(gpu, orc, cornell, scene_io, procedural):
         print("LBVH cornell: %d nodes depth %d build %.2f ms" % (ctx.stats()["bvh_nodes"], ctx.stats()["bvh_depth"], ctx.stats()["bvh_build_ms"]))
     finally:
         ctx.close()
+
+
+def test_group_scene_replica_is_a_clone(gpu, cube, scene_io):
+    """pt_group_upload_scene builds the BVH once and clones the scene into the other devices' contexts (pti::clone_scene): a cloned
+    context renders the same image and accepts a material hot-swap like the original (two contexts on device 0)."""
+    tex = scene_io.checker_texture()
+    _upload(gpu, cube, textures=[tex], mesh_textures=[0], env=B.make_env(use_auto=True, intensity=1.0))
+    W, H = 128, 96
+    cam = _cam(cube, W, H)
+    want, want8 = gpu.render(cam, W, H, 16, 4, want_rgba8=True)
+    other = B.Context(0)
+    try:
+        other.clone_scene_from(gpu)
+        got, got8 = other.render(cam, W, H, 16, 4, want_rgba8=True)
+        assert_bitwise(got, want, "cloned scene")
+        np.testing.assert_array_equal(got8, want8)
+        assert other.stats()["bvh_nodes"] == gpu.stats()["bvh_nodes"] and other.quad_info() == gpu.quad_info()
+        mats = np.stack([m for _, m, _ in cube["materials"]]).copy()
+        mats[0, 4] = 0.9
+        gpu.set_materials(mats); other.set_materials(mats)
+        a, _ = gpu.render(cam, W, H, 16, 4); b, _ = other.render(cam, W, H, 16, 4)
+        assert_bitwise(a, b, "cloned scene after pt_set_materials")
+        assert not (a.view(np.uint32) == want.view(np.uint32)).all()
+    finally:
+        other.close()
