@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 #define PT_MAT_FLOATS 17 /* material_data: device_global.hpp:19-36, 68 bytes, field order kept */
 
 enum {
@@ -89,6 +89,9 @@ typedef struct pt_stats {
      * scheduler iterations, sum of idle lanes, sum of finished lanes awaiting retirement, sum of node+leaf lanes} */
     uint64_t sched[32];
     double prepass_ms;      /* part of kernel_ms spent in the cost pre-pass launch + queue sort (0 when the schedule has none) */
+    /* counted renders, group walk of sparse waves (eight lanes per ray): {phases, iterations, sum of busy groups, of groups at a
+     * node, of groups at a leaf, rays traced, shader-clock cycles, 0} */
+    uint64_t groups[8];
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */

@@ -18,8 +18,8 @@ extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const flo
 extern "C" size_t pt_sort_scratch_bytes(uint32_t n);
 extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0,
                                             uint32_t* scratch, uint8_t* bucket, hipStream_t stream);
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
-                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu);
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
+                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 extern "C" int pt_debug_block(void);
 extern "C" size_t pt_lbvh_workspace_bytes(int n);
 extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_size, void* d_workspace, size_t workspace_bytes, PtNode* d_nodes, uint32_t* d_order,
@@ -244,7 +244,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
-        DevBuf* bufs[] = {&c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
+        DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
                           &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
@@ -280,6 +280,8 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value != 0 && value != 1) return fail(c, PT_E_INVALID, "bvh_builder must be 0 (host binned SAH) or 1 (device LBVH)");
         c->bvh_builder = (int)value;
     }
+    else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
+    else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -392,6 +394,8 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_nodes = c->bvh.nodes.size();
     pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
+    pt_bvh_collapse8(c->bvh, &c->nodes8, &c->root8, &c->depth8);
+    if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
     { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
         const size_t n_slots = c->bvh.tris.size();
         std::vector<PtShade> by_leaf(n_slots);
@@ -434,6 +438,7 @@ int upload_scene_to_device(pt_ctx* c)
     int rc;
     if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
     if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
+    if ((rc = upload(c, c->d_nodes8, c->nodes8.data(), c->nodes8.size() * sizeof(PtNode8)))) return rc;
     if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
     if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
     for (void* p : c->d_textures) (void)hipFree(p);
@@ -465,6 +470,9 @@ int clone_scene(pt_ctx* dst, const pt_ctx* src)
     dst->nodes4 = src->nodes4;
     dst->root4 = src->root4;
     dst->depth4 = src->depth4;
+    dst->nodes8 = src->nodes8;
+    dst->root8 = src->root8;
+    dst->depth8 = src->depth8;
     dst->shade = src->shade;
     dst->materials = src->materials;
     dst->n_materials = src->n_materials;
@@ -550,15 +558,22 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.nodes4 = (const PtNode4*)c->d_nodes4.p;
         P.root = c->root4;
         P.stack_entries = 3 * c->depth4 + 1;
+        P.coop = c->coop;
+    }
+    if (c->kernel == 2 && c->groups && !c->nodes8.empty()) { // group walk of sparse waves (oct nodes)
+        P.nodes8 = (const PtNode8*)c->d_nodes8.p;
+        P.root8 = c->root8;
+        P.groups = c->groups;
     }
 
     // Launch geometry.  The wavefront kernel keeps `ns` pixels in flight per wave; shrink ns when the image is too small to give
     // every resident wave a full set (e.g. 512x512 over 4096 waves), otherwise use the default.
+    const int group_entries = P.nodes8 ? 7 * c->depth8 + 1 : 0;
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
     int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
     {
-        const hipError_t ge = pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ);
+        const hipError_t ge = pt_kernel_geometry(c->kernel, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         if (ge == hipErrorInvalidConfiguration)
             return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
         HIP_TRY(c, ge);
@@ -568,7 +583,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, want_ns, &block, &lds, &ns, &state_words, &vg, &occ));
+            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -814,6 +829,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
             c->stats.samples = h.samples; c->stats.rays = h.rays; c->stats.nodes = h.nodes; c->stats.tris = h.tris;
             c->stats.scatters = h.scatters; c->stats.env_misses = h.env_misses; c->stats.nan_retries = h.nan_retries;
             for (int i = 0; i < 32; ++i) c->stats.sched[i] = h.sched[i];
+            for (int i = 0; i < 8; ++i) c->stats.groups[i] = h.grp[i];
         }
     }
     *out = c->stats;

@@ -262,6 +262,73 @@ void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4,
     }
 }
 
+void pt_bvh_collapse8(const PtBvh& b, std::vector<PtNode8>* out, int32_t* root8, int* depth8)
+{
+    out->clear();
+    *root8 = b.root;
+    *depth8 = 0;
+    if (b.root < 0) return; // empty scene or a leaf as root: no oct nodes
+    struct Slot { float lo[3], hi[3]; int32_t ref; };
+    auto area = [](const Slot& s) {
+        const float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto child_slot = [&](const PtNode& nd, int side) {
+        Slot s;
+        for (int a = 0; a < 3; ++a) { s.lo[a] = nd.lo[a][side]; s.hi[a] = nd.hi[a][side]; }
+        s.ref = side ? nd.right : nd.left;
+        return s;
+    };
+    struct Item { int32_t node2; int32_t idx8; int depth; };
+    std::vector<Item> todo;
+    out->emplace_back();
+    todo.push_back({b.root, 0, 1});
+    *root8 = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        *depth8 = std::max(*depth8, it.depth);
+        Slot slots[8];
+        int n = 0;
+        {
+            const PtNode& nd = b.nodes[(size_t)it.node2];
+            for (int side = 0; side < 2; ++side)
+                if ((side ? nd.right : nd.left) != -1) slots[n++] = child_slot(nd, side);
+        }
+        while (n < 8) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < n; ++k)
+                if (slots[k].ref >= 0) {
+                    const float ar = area(slots[k]);
+                    if (ar > best_area) { best_area = ar; best = k; }
+                }
+            if (best < 0) break;
+            const PtNode& cn = b.nodes[(size_t)slots[best].ref];
+            slots[best] = child_slot(cn, 0); // children keep their relative order: left in place, right appended
+            slots[n++] = child_slot(cn, 1);
+        }
+        PtNode8 q;
+        for (int k = 0; k < 8; ++k) {
+            for (int a = 0; a < 3; ++a) q.c[k].lo[a] = q.c[k].hi[a] = INFINITY; // never hit (empty slot)
+            q.c[k].ref = -1;
+            q.c[k].pad = 0;
+        }
+        for (int k = 0; k < n; ++k) {
+            for (int a = 0; a < 3; ++a) { q.c[k].lo[a] = slots[k].lo[a]; q.c[k].hi[a] = slots[k].hi[a]; }
+            if (slots[k].ref >= 0) {
+                const int32_t idx = (int32_t)out->size();
+                out->emplace_back();
+                q.c[k].ref = idx;
+                todo.push_back({slots[k].ref, idx, it.depth + 1});
+            } else {
+                q.c[k].ref = slots[k].ref;
+            }
+        }
+        (*out)[(size_t)it.idx8] = q;
+    }
+}
+
 void pt_bvh_layout(PtBvh* b, int sibling_pairs, int leaf_align)
 {
     if (sibling_pairs) layout_sibling_pairs(b);

@@ -31,3 +31,9 @@ void pt_bvh_collapse4(const PtBvh& bvh, std::vector<PtNode4>* out, int32_t* root
 // Host mirror of the kernel's traversal over the product BVH (validation only, never on the render path).
 bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u,
                              float* v, int32_t* prim);
+
+// Three-level collapse into oct nodes (PtNode8, pt_types.h): starting from the two children of a binary node, the internal slot with
+// the largest surface area is replaced by its two children until eight slots are used (or none is internal).  root8 = 0 when the
+// root is an internal node (else the binary root reference), depth8 = deepest chain of oct nodes (the group walk pushes at most
+// seven entries per level).
+void pt_bvh_collapse8(const PtBvh& bvh, std::vector<PtNode8>* out, int32_t* root8, int* depth8);

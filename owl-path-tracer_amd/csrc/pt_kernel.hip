@@ -80,6 +80,8 @@ struct Counters {
     unsigned long long cyc[8] = {}; // COUNT build: shader-clock cycles per phase {node steps, tri steps, retire, hit pass, miss pass, park/resume, sleep, total}
     uint32_t sched[32] = {}; // wave-uniform scheduler census (wavefront kernel)
     uint32_t depth[4] = {};  // per lane: pushes, pushes at stack depth >= 8 / 12 / 16
+    uint32_t grp[6] = {};    // wave-uniform census of the group walk: phases, iterations, busy groups, node groups, leaf groups, rays
+    unsigned long long grp_cyc = 0;
 };
 
 // Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
@@ -222,12 +224,22 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
 // Quad-node step (PtNode4, pt_types.h): the four grandchild boxes of a binary node in one 128-byte record - one cache line and
 // one memory round trip per TWO levels of the binary tree.  Slab test as in node_step, two packed pairs; the lane continues with
 // the nearest hit child and pushes the other hit children (in slot order; any visiting order gives the same closest hit).
-template <int STRIDE, int LDS_ENTRIES>
-__device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest, int& cur, int& sp)
+// COOP: the record was staged in LDS by node4_fetch_coop (below); `rec` = this lane's 128 bytes there, chunk k at position k ^ rot.
+// Otherwise the lane reads its own record with 7 x global_load_dwordx4 = 7 vL1D accesses per lane and step.
+template <int STRIDE, int LDS_ENTRIES, bool COOP>
+__device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, const uint32_t* rec, int rot, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest,
+                                           int& cur, int& sp)
 {
-    const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4);
-    const f32x4 lx = ldg4(nodes4, nb), ly = ldg4(nodes4, nb + 16), lz = ldg4(nodes4, nb + 32);
-    const f32x4 hx = ldg4(nodes4, nb + 48), hy = ldg4(nodes4, nb + 64), hz = ldg4(nodes4, nb + 80), cf = ldg4(nodes4, nb + 96);
+    f32x4 lx, ly, lz, hx, hy, hz, cf;
+    if (COOP) {
+        lx = *(const f32x4*)(rec + ((0 ^ rot) << 2)); ly = *(const f32x4*)(rec + ((1 ^ rot) << 2)); lz = *(const f32x4*)(rec + ((2 ^ rot) << 2));
+        hx = *(const f32x4*)(rec + ((3 ^ rot) << 2)); hy = *(const f32x4*)(rec + ((4 ^ rot) << 2)); hz = *(const f32x4*)(rec + ((5 ^ rot) << 2));
+        cf = *(const f32x4*)(rec + ((6 ^ rot) << 2));
+    } else {
+        const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4);
+        lx = ldg4(nodes4, nb); ly = ldg4(nodes4, nb + 16); lz = ldg4(nodes4, nb + 32);
+        hx = ldg4(nodes4, nb + 48); hy = ldg4(nodes4, nb + 64); hz = ldg4(nodes4, nb + 80); cf = ldg4(nodes4, nb + 96);
+    }
     const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const f32x2 pad = {1.0000004f, 1.0000004f};
     float tn[4];
@@ -287,6 +299,39 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     } else {
         cur = PT_DONE;
     }
+}
+
+// Cooperative fetch of the quad nodes of all lanes (round 3, option "coop", default on).  The vector L1 serves about one access
+// per cycle and CU when every lane of a load addresses its own cache line, and a dwordx4 instruction costs it ~25 cycles even
+// with few lanes (tools/node_fetch_bench.hip, profiles/r03_node_fetch.md): seven per-lane loads of one 128-byte record are seven
+// accesses per lane.  Here 8 lanes fetch ONE record as one whole cache line - round r, lane i reads 16 bytes of the record of
+// lane 8r + i/8 - straight into a wave-private LDS staging area (global_load_lds_dwordx4: no VGPR round trip), and every lane
+// then reads its own record back with 7 x ds_read_b128: one L1 access per record instead of seven, 2x the record rate in the
+// bench (85 -> 150-168 G records/s chip-wide).  Chunk k of owner lane n is staged at position k ^ ((n >> 1) & 7) of the
+// record's 128 bytes: the b128 reads of a lane group {0-3, 12-15, 20-27, ...} then hit distinct banks (an unswizzled image is
+// an 8-way conflict: records are 128 bytes apart).  Rounds whose eight owner lanes have no node to fetch are skipped.
+// Wave-uniform control flow: call it from all lanes; node4_step<.., true> then reads the lane's record from stage + 32 * lane.
+#define PT_STAGE_BYTES (PT_WAVE * (int)sizeof(PtNode4))
+#define PT_AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ void node4_fetch_coop(const PtNode4* __restrict__ nodes4, uint32_t* stage, int lane, int cur)
+{
+    const unsigned long long m = __ballot(cur >= 0);
+    const int g = lane >> 3, sub = lane & 7;
+    // owner of round r is lane 8r + g, its rotation (4r + (g >> 1)) & 7: the chunk this lane fetches alternates between two values
+    const uint32_t c_even = (uint32_t)((sub ^ (g >> 1)) << 4), c_odd = c_even ^ 64u;
+    int refs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) refs[r] = __builtin_amdgcn_ds_bpermute((8 * r + g) * 4, cur);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (((uint32_t)(m >> (8 * r)) & 0xffu) != 0u) { // wave-uniform
+            if (refs[r] >= 0) {
+                const uint32_t off = ((uint32_t)refs[r] << 7) + ((r & 1) ? c_odd : c_even);
+                __builtin_amdgcn_global_load_lds((const void PT_AS1*)((const char PT_AS1*)nodes4 + off), (void PT_AS3*)(stage + r * 256), 16, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // LDS-DMA data is ordered for this wave's ds_read by its own vmcnt
 }
 
 template <bool COUNT>
@@ -608,6 +653,9 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
         for (int k = 0; k < 24; ++k) atomicAdd(&P.counters->sched[k], (unsigned long long)cn.sched[k]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&P.counters->sched[24 + k], cn.cyc[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&P.counters->grp[k], (unsigned long long)cn.grp[k]);
+        atomicAdd(&P.counters->grp[6], cn.grp_cyc);
     }
     for (int k = 0; k < 4; ++k) {
         unsigned long long x = cn.depth[k];
@@ -716,11 +764,19 @@ enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ,
 #define PT_FRESH 0xffffffffu // S_PIX marker: slot has no (pixel, chunk) running; S_RNG then holds the ticket it waits on, or PT_FRESH
 enum { K_PSLOT = 0, K_CUR, K_SP, K_BT, K_BU, K_BV, K_BSLOT, K_BID, K_PEND, K_NFIELDS };
 
-static inline int pt_wave_lds_stack(int stack_entries) { return stack_entries < PT_LDS_STACK ? stack_entries : PT_LDS_STACK; }
-static inline size_t pt_wave_lds_bytes(int stack_entries, int ns)
+// LDS stack levels of a wave: the top PT_LDS_STACK levels of the per-lane stacks (fewer for a shallow tree), but at least what the
+// group walk needs (group_entries entries in eight columns per group; <= PT_GROUP_STACK = 8 * PT_LDS_STACK)
+static inline int pt_wave_lds_stack(int stack_entries, int group_entries)
 {
-    return ((size_t)pt_wave_lds_stack(stack_entries) * PT_WAVE + (size_t)(L_NFIELDS + S_NFIELDS) * ns) * 4 + (((size_t)3 * ns + 15) & ~(size_t)15);
+    const int a = stack_entries < PT_LDS_STACK ? stack_entries : PT_LDS_STACK, b = (group_entries + 7) / 8;
+    return a > b ? a : b;
 }
+static inline size_t pt_wave_lds_bytes(int stack_entries, int group_entries, int ns, int coop)
+{
+    return (coop ? (size_t)PT_WAVE * sizeof(PtNode4) : 0) + ((size_t)pt_wave_lds_stack(stack_entries, group_entries) * PT_WAVE + (size_t)(L_NFIELDS + S_NFIELDS) * ns) * 4 +
+           (((size_t)3 * ns + 15) & ~(size_t)15);
+}
+static_assert(PT_GROUP_STACK <= 8 * PT_LDS_STACK, "a group's stack is eight columns of the LDS stack area");
 static inline size_t pt_wave_state_words(int stack_entries)
 {
     int ovf = stack_entries > PT_LDS_STACK ? stack_entries - PT_LDS_STACK : 0;
@@ -912,6 +968,179 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 }
 } // namespace
 
+// =====================================================================================================================
+// Group walk: the traversal of a SPARSE wave (round 3)
+// =====================================================================================================================
+// A wave with few rays to trace wastes its lanes in the per-lane walk: a node step costs the same wave-instructions for 4 busy
+// lanes as for 64, the vector L1 spends ~25 cycles on a load instruction however few lanes it has, and a ray still needs its
+// ~12 dependent quad-node steps plus leaf steps - 25-40 us per ray where a dense wave manages 10 (profiles/r02_summary.md).  That
+// regime is the tail of every frame and most of a frame whose pixels all start at once (one rank's shard of a multi-GPU frame,
+// small images), and a pixel is one sequential chain of rays (device.cu:226-243), so the frame waits for it.
+// Here EIGHT LANES WALK ONE RAY: the tree is read as oct nodes (PtNode8: up to eight descendants of a binary node, three binary
+// levels per record), lane k of a group tests child k (two 16-byte loads: the eight lanes fetch the record's two cache lines
+// coalesced), the group finds the nearest hit child with three DPP steps, pushes the other hit children on the group's stack
+// and continues with the nearest; at a leaf, lane k tests triangle k and the group reduces (t, id) lexicographically.  A ray goes
+// down the tree in a third of the dependent steps, every step is one memory round trip for up to eight rays, and a wave needs
+// eight rays, not sixty-four, to fill its lanes.  Node groups and leaf groups are served in the SAME iteration (their loads are in
+// flight together), so no ray waits for a majority.
+// The closest hit does not depend on the visiting order (tri_eval's tie-break on the triangle id, conservative boxes), so the
+// image is bit-identical to the per-lane walk's - the parity suite runs with the group walk forced on as well (option groups = 2).
+// A group's stack is eight adjacent columns of the per-lane LDS stack area: entry e at stack[(e >> 3) * 64 + 8 * group + (e & 7)]
+// (capacity 8 * levels; the host enables the group walk only if 7 * depth8 + 1 entries fit, pt_api.cpp).
+#ifndef PT_GROUP_MAX_RAYS
+#define PT_GROUP_MAX_RAYS 16 // ray-queue level up to which a traversal phase uses the group walk (option groups = 1)
+#endif
+#ifndef PT_GROUP_MAX_RUN
+#define PT_GROUP_MAX_RUN 24  // running pixels of the wave up to which it counts as sparse
+#endif
+
+namespace {
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ uint32_t dpp_mir8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); } // row_half_mirror
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// one reduction stage of the leaf step: take the partner's candidate if it is better ((t, id) lexicographic)
+#define PT_HIT_STAGE(DPP)                                                                                           \
+    {                                                                                                               \
+        const float t2 = __uint_as_float(DPP(__float_as_uint(hc.t)));                                               \
+        const int id2 = (int)DPP((uint32_t)hc.id);                                                                  \
+        const uint32_t u2 = DPP(__float_as_uint(hc.u)), v2 = DPP(__float_as_uint(hc.v)), s2 = DPP((uint32_t)hc.slot); \
+        const bool better = t2 < hc.t || (t2 == hc.t && id2 < hc.id);                                               \
+        hc.t = better ? t2 : hc.t; hc.id = better ? id2 : hc.id;                                                    \
+        hc.u = better ? __uint_as_float(u2) : hc.u; hc.v = better ? __uint_as_float(v2) : hc.v;                     \
+        hc.slot = better ? (int)s2 : hc.slot;                                                                       \
+    }
+
+template <bool COUNT>
+__device__ __forceinline__ void traverse_groups(const PtKernelParams& P, WaveCtx& w, int lane, uint32_t* stack0, Counters& cn)
+{
+    const int ns = w.ns;
+    uint32_t* lray = w.lray;
+#define LF(f, s) lray[(f) * ns + (s)]
+#define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
+    const PtNode8* __restrict__ nodes8 = P.nodes8;
+    const PtTri* __restrict__ tris = P.tris;
+    const int sub = lane & 7, gbase = lane & 56;
+    const bool lead = sub == 0;
+    uint32_t* gstack = stack0 + gbase; // entry e: gstack[(e >> 3) * 64 + (e & 7)]
+    int pslot = -1, cur = PT_DONE, sp = 0;
+    Hit h;
+    h.t = kTMax; h.u = h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
+    v3 o = vs(0.0f), d = vs(1.0f), inv = vs(1.0f);
+    int n_iter = 0;
+    for (;;) {
+        if (++n_iter > (1 << 22)) { // as in the per-lane walk: a corrupt reference must not spin
+            if (lane == 0) gp(P.error_flag)[0] = 1u;
+            break;
+        }
+        // ---- retire finished groups (the leader writes the hit over the ray origin), refill idle groups from the ray queue ----
+        const bool fin = pslot >= 0 && cur == PT_DONE;
+        if (__ballot(fin) != 0ull || __ballot(pslot < 0) != 0ull) {
+            const bool fin_hit = fin && lead && h.slot >= 0, fin_miss = fin && lead && h.slot < 0;
+            const unsigned long long m_fh = __ballot(fin_hit), m_fm = __ballot(fin_miss);
+            if (fin_hit) {
+                LF(L_AX, pslot) = __float_as_uint(h.u);
+                LF(L_AY, pslot) = __float_as_uint(h.v);
+                LF(L_AZ, pslot) = (uint32_t)h.slot;
+                w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_fh))] = (uint8_t)pslot;
+            }
+            if (fin_miss) w.missq[w.wrap(w.wrap(w.miss_head + w.miss_count) + rank_in(m_fm))] = (uint8_t)pslot;
+            if (fin) pslot = -1;
+            w.hit_count += popc64(m_fh);
+            w.miss_count += popc64(m_fm);
+            const unsigned long long m_idle = __ballot(pslot < 0); // whole groups
+            const int n_idle = popc64(m_idle) >> 3;
+            const int take = n_idle < w.ray_count ? n_idle : w.ray_count;
+            if (take > 0) {
+                const int rk = rank_in(m_idle) >> 3; // rank of this lane's group among the idle groups
+                if (pslot < 0 && rk < take) {
+                    pslot = (int)w.rayq[w.wrap(w.ray_head + rk)];
+                    o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
+                    d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
+                    inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    cur = P.root8; // an oct node, or the leaf code of a scene of <= leaf_size triangles
+                    sp = 0;
+                    h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
+                }
+                w.ray_head = w.wrap(w.ray_head + take);
+                w.ray_count -= take;
+                if (COUNT) cn.grp[5] += take;
+            }
+            if (__ballot(pslot >= 0) == 0ull) break; // every ray of this phase is in the hit or the miss queue
+        }
+        // ---- one step for every group: the loads of the node groups and of the leaf groups are in flight together ----
+        const bool is_node = cur >= 0, is_leaf = cur < PT_DONE;
+        if (COUNT) {
+            cn.grp[1] += 1; cn.grp[2] += popc64(__ballot(pslot >= 0)) >> 3;
+            cn.grp[3] += popc64(__ballot(is_node)) >> 3; cn.grp[4] += popc64(__ballot(is_leaf)) >> 3;
+        }
+        const uint32_t code = ~(uint32_t)cur;
+        const int first = (int)(code >> 3), count = is_leaf ? (int)(code & 7u) : 0;
+        const bool tri_on = sub < count;
+        // unconditional loads (idle lanes read record 0): one basic block, every request in flight before the first wait
+        const size_t nb = is_node ? (size_t)(uint32_t)cur * sizeof(PtNode8) + (size_t)sub * 32 : 0;
+        const f32x4 c0 = ldg4(nodes8, nb), c1 = ldg4(nodes8, nb + 16);
+        const size_t tb = tri_on ? (size_t)(uint32_t)(first + sub) * sizeof(PtTri) : 0;
+        const f32x4 ta = ldg4(tris, tb), tb4 = ldg4(tris, tb + 16), tc = ldg4(tris, tb + 32);
+        if (COUNT && lead) { cn.nodes += is_node ? 4u : 0u; cn.tris += (uint32_t)count; } // an oct node is four 64-byte units
+        // -- node groups: lane k tests child k
+        float tn = 0.0f;
+        const int ref = __float_as_int(c1.z);
+        bool hit = false;
+        if (is_node) hit = box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
+        // entry distance with the child index in its low bits: unique within the group, ordered like the distance (tn >= kTMin > 0)
+        const uint32_t key = hit ? ((__float_as_uint(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
+        uint32_t kmin = umin_(key, dpp_xor1(key));
+        kmin = umin_(kmin, dpp_xor2(kmin));
+        kmin = umin_(kmin, dpp_mir8(kmin));
+        const bool any = kmin != 0xffffffffu;
+        const bool push = hit && key != kmin;
+        const unsigned long long m_push = __ballot(push);
+        const uint32_t pbits = (uint32_t)(m_push >> gbase) & 0xffu; // this group's pushing lanes
+        const int prank = __builtin_popcount(pbits & ((1u << sub) - 1u)), pcnt = __builtin_popcount(pbits);
+        if (push) {
+            const int e = sp + prank;
+            gstack[(e >> 3) * PT_WAVE + (e & 7)] = (uint32_t)ref;
+        }
+        const int near_ref = __builtin_amdgcn_ds_bpermute((gbase | (int)(kmin & 7u)) << 2, ref);
+        // -- leaf groups: lane k tests triangle k; (t, id)-lexicographic minimum over the group, payload (u, v, slot)
+        Hit hc = h;
+        if (tri_on) tri_eval(ta, tb4, tc, first + sub, o, d, hc);
+        PT_HIT_STAGE(dpp_xor1)
+        PT_HIT_STAGE(dpp_xor2)
+        PT_HIT_STAGE(dpp_mir8)
+        h = hc; // unchanged where the group is not at a leaf: all its lanes held the same candidate
+        // -- next reference
+        if (is_node) sp += pcnt;
+        if (is_node && any) {
+            cur = near_ref;
+        } else if (is_node || is_leaf) {
+            if (sp > 0) {
+                --sp;
+                cur = (int)gstack[(sp >> 3) * PT_WAVE + (sp & 7)];
+            } else {
+                cur = PT_DONE;
+            }
+        }
+    }
+#undef LF
+#undef LFF
+}
+} // namespace
+
+// a lane that arrives at a leaf stashes it and continues with the next node on its stack (speculative traversal)
+#define PT_STASH_LEAF(ENTRIES)                                                       \
+    if (cur < PT_DONE && pend == PT_DONE) {                                          \
+        pend = cur;                                                                  \
+        if (sp > 0) {                                                                \
+            --sp;                                                                    \
+            cur = (int)stack_pop<PT_WAVE, ENTRIES>(stack, ovf, sp);                  \
+        } else {                                                                     \
+            cur = PT_DONE;                                                           \
+        }                                                                            \
+    }
+
 // The instrumented instance gets 256 VGPRs (2 waves/SIMD): with 128 it spills ~50 registers to scratch, and a spilling build of this
 // kernel rendered wrong pixels in round 1 (both instrumented instances, identical source otherwise; never the 128-VGPR product
 // instance, which does not spill).  pt_render refuses to launch any instance that needs scratch (pt_kernel_geometry).
@@ -925,9 +1154,13 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const int ns = P.ns;
-    const int lds_stack = P.stack_entries < PT_LDS_STACK ? P.stack_entries : PT_LDS_STACK;
-    uint32_t* stack = lds + lane;                   // stack[level * 64], levels < PT_LDS_STACK
-    uint32_t* lray = lds + lds_stack * PT_WAVE;     // lray[field * ns + slot]
+    const int lds_stack = P.lds_levels; // pt_wave_lds_stack(), from the host
+    // cooperative node fetch (P.coop): the first 8 KB of the wave's LDS are the staging area of node4_fetch_coop
+    const bool coop = P.coop != 0 && P.nodes4 != nullptr;
+    uint32_t* stage = lds;
+    uint32_t* lds0 = lds + (coop ? PT_STAGE_BYTES / 4 : 0);
+    uint32_t* stack = lds0 + lane;                   // stack[level * 64], levels < PT_LDS_STACK
+    uint32_t* lray = lds0 + lds_stack * PT_WAVE;     // lray[field * ns + slot]
     uint32_t* lstate = lray + L_NFIELDS * ns;       // lstate[field * ns + slot]
     const int ovf_levels = P.stack_entries > PT_LDS_STACK ? P.stack_entries - PT_LDS_STACK : 0;
     uint32_t PT_AS1* park = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE) + lane; // park[field * 64]
@@ -1001,6 +1234,10 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
             __builtin_amdgcn_s_sleep(64);
             w.miss_blocked = false;
             if (COUNT) { cn.sched[18] += 1; cn.cyc[6] += __builtin_amdgcn_s_memtime() - t0; }
+        } else if (P.nodes8 != nullptr && n_parked == 0 && (P.groups == 2 || (w.ray_count <= PT_GROUP_MAX_RAYS && w.n_run <= PT_GROUP_MAX_RUN))) {
+            // sparse wave: eight lanes per ray (no parking: the phase ends when all its rays are in the hit / miss queues)
+            traverse_groups<COUNT>(P, w, lane, lds0, cn);
+            if (COUNT) { cn.grp[0] += 1; cn.grp_cyc += __builtin_amdgcn_s_memtime() - t0; }
         } else {
             // ======================= TRAVERSAL PHASE ==============================================================
             int pslot = -1;
@@ -1090,7 +1327,8 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
                     if (m_busy == 0ull) break;                                                           // nothing in flight
                     if (++n_retire_passes >= 16) w.miss_blocked = false; // time to poll the waiting tickets again
                     // a full shading batch is ready: go and turn it into rays (a miss queue that only holds unpublished tickets does not count)
-                    if (pick_pass(w, false) != PICK_NONE) break; // a shading batch is due: go and turn it into rays
+                    // (a sparse wave stays until its rays are done: nothing parked, so the next phase can be a group walk)
+                    if (pick_pass(w, false) != PICK_NONE && !(P.groups == 1 && w.n_run <= PT_GROUP_MAX_RUN && w.ray_count == 0)) break;
                     continue;
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
@@ -1121,27 +1359,29 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
 #pragma unroll
                         for (int rep = 0; rep < PT_NODE_REPS; ++rep) {
                             if (rep >= n_reps) break;
-                            if (cur >= 0) {
-                                if (COUNT) cn.nodes += nodes4 ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
-                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff>(nodes4, stack, ovf, o, inv, h.t, cur, sp);
-                                else node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
-                                if (cur < PT_DONE && pend == PT_DONE) { // stash the leaf, continue with the next node on the stack
-                                    pend = cur;
-                                    if (sp > 0) {
-                                        --sp;
-                                        cur = (int)stack_pop<PT_WAVE, 0x7fffffff>(stack, ovf, sp);
-                                    } else {
-                                        cur = PT_DONE;
-                                    }
+                            if (coop) { // all lanes: 8 lanes fetch one record
+                                node4_fetch_coop(nodes4, stage, lane, cur);
+                                if (cur >= 0) {
+                                    if (COUNT) cn.nodes += 2; // a quad node is two binary nodes' worth of boxes (128 B)
+                                    node4_step<PT_WAVE, 0x7fffffff, true>(nodes4, stage + lane * 32, (lane >> 1) & 7, stack, ovf, o, inv, h.t, cur, sp);
+                                    PT_STASH_LEAF(0x7fffffff);
                                 }
                             }
+#ifndef PT_COOP_ONLY
+                            else if (cur >= 0) {
+                                if (COUNT) cn.nodes += nodes4 ? 2 : 1;
+                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                                else node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                                PT_STASH_LEAF(0x7fffffff);
+                            }
+#endif
                         }
 #if PT_NODE_KEEP > 0
                       }
 #endif
-                    } else if (cur >= 0) {
+                    } else if (cur >= 0) { // some stack of the wave is about to leave LDS (rare): per-lane fetch, overflow-aware pushes
                         if (COUNT) cn.nodes += nodes4 ? 2 : 1;
-                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp);
+                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
                         else node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
                         if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;
@@ -1406,14 +1646,15 @@ extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const flo
 
 // Launch geometry of a render variant: block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for
 // the wavefront kernel), per-block global state words, registers, occupancy.
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int want_ns, int* block, size_t* lds_bytes, int* ns,
-                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu)
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
+                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels)
 {
     const void* fn;
     if (variant == 1) {
         fn = count ? (const void*)pt_render_kernel<true> : (const void*)pt_render_kernel<false>;
         *block = PT_BLOCK;
         *lds_bytes = (size_t)stack_entries * PT_BLOCK * 4;
+        *lds_levels = stack_entries;
         *ns = PT_BLOCK;
         *state_words_per_block = 0;
     } else {
@@ -1421,7 +1662,8 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         int n = want_ns < 16 ? 16 : (want_ns > 255 ? 255 : want_ns);
         *block = PT_WAVE;
         *ns = n;
-        *lds_bytes = pt_wave_lds_bytes(stack_entries, n);
+        *lds_bytes = pt_wave_lds_bytes(stack_entries, group_entries, n, coop);
+        *lds_levels = pt_wave_lds_stack(stack_entries, group_entries);
         *state_words_per_block = pt_wave_state_words(stack_entries);
     }
     hipFuncAttributes fa;

@@ -30,6 +30,21 @@ struct PtNode4 {
 };
 static_assert(sizeof(PtNode4) == 128, "PtNode4 must be 128 bytes");
 
+// Three binary levels per record ("oct node", round 3): up to eight descendants of a binary node, each with its own box - the
+// record of the group walk (pt_kernel.hip, traverse_groups), where eight lanes test the eight children of ONE ray's node at once:
+// lane k of a group reads child k (2 x global_load_dwordx4; the eight lanes cover the record's two cache lines), so a ray goes down
+// the tree in a third of the dependent steps of the binary walk.  Built by pt_bvh_collapse8 from the PtNode[] tree (same boxes and
+// leaves; the slot with the largest box is opened until eight are used).  ref >= 0: oct node index; < -1: leaf code as in PtNode;
+// -1: empty slot (box {+inf, +inf}: never hit).
+struct PtNode8 {
+    struct Child {
+        float lo[3], hi[3];
+        int32_t ref;
+        uint32_t pad;
+    } c[8];
+};
+static_assert(sizeof(PtNode8) == 256, "PtNode8 must be 256 bytes");
+
 // One triangle in LEAF order: the three vertices (the reference's vertex_buffer values, fetched through
 // index_buffer: device.cu:42-61) + its global id (entity order, then face order).  48 bytes = 3 x dwordx4.
 struct PtTri {
@@ -52,6 +67,7 @@ static_assert(sizeof(PtShade) == 64, "PtShade must be 64 bytes");
 
 #define PT_MAT_STRIDE 20 // material_data (17 floats) + texture slot + 2 pad: 80 bytes, 16-byte aligned rows
 #define PT_MAX_STACK 64
+#define PT_GROUP_STACK 96 // entries of a group's stack in the group walk: eight columns of the 12-level LDS stack area
 
 struct PtTexDesc {
     const uint32_t* texels;
@@ -62,6 +78,8 @@ struct PtCounters {
     unsigned long long samples, rays, nodes, tris, scatters, env_misses, nan_retries;
     // scheduler census of the wavefront kernel (wave-level events and the lanes that took part in them)
     unsigned long long sched[32];
+    // group walk (sparse waves): {phases, iterations, sum of busy groups, sum of node groups, sum of leaf groups, rays traced, shader-clock cycles, unused}
+    unsigned long long grp[8];
 };
 
 #define PT_MAX_TAIL_CHUNKS 20
@@ -105,6 +123,7 @@ struct PtKernelParams {
     int32_t sample_begin, sample_count; // this launch covers [sample_begin, sample_begin + sample_count)
     int32_t max_depth;
     int32_t stack_entries;
+    int32_t lds_levels;        // wavefront kernel: stack levels kept in LDS (pt_wave_lds_stack)
     int32_t ns;                // wavefront kernel: path slots per wave (64..255)
     int32_t chunk_spp, n_chunks; // wavefront kernel: samples per (pixel, chunk) ticket and chunks per pixel
     uint32_t n_tickets;        // n_pixels * n_chunks
@@ -113,5 +132,9 @@ struct PtKernelParams {
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];
     const PtNode4* nodes4;     // wavefront kernel: quad nodes (null: walk PtNode[] one level per step); root / stack_entries then refer to them
+    const PtNode8* nodes8;     // wavefront kernel: oct nodes of the group walk (null: no group walk)
+    int32_t root8;             // root reference into nodes8 (leaf code if the scene is tiny)
+    int32_t groups;            // group walk: 0 = never, 1 = when a wave has few rays to trace (sparse wave), 2 = always (tests)
+    int32_t coop;              // wavefront kernel, quad nodes: 1 = cooperative node fetch through an LDS staging area (node4_fetch_coop), 0 = per-lane loads
     int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
 };

@@ -51,11 +51,12 @@ class Stats(C.Structure):
                 ("block", C.c_int32), ("grid", C.c_int32), ("stack_entries", C.c_int32),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("scatters", C.c_uint64),
                 ("env_misses", C.c_uint64), ("nan_retries", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double)]
+                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["sched"] = list(self.sched)
+        d["groups"] = list(self.groups)
         return d
 
 

@@ -547,6 +547,57 @@ def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
     gpu.set_option("kernel", 2)
 
 
+def test_group_walk_bitwise(gpu, orc, cornell, scene_io, procedural):
+    """Round 3: the group walk (eight lanes per ray over oct nodes, pt_kernel.hip traverse_groups) is what a SPARSE wave traverses
+    with.  Closest hit does not depend on the visiting order, so forcing it on for every ray (groups = 2), leaving it to the sparse
+    waves (1, default) and switching it off (0) must give one image, bit for bit - against the oracle on the small scenes, against
+    each other on every pixel of the full-size C4 frame (deep tree: 871 k triangles)."""
+    env = dict(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=B.make_env(**env))
+    W = H = 128
+    cam = _cam(cornell, W, H)
+    S = orc.Scene(cornell["flat"])
+    want, _, cnt = S.render(_ocam(orc, cam), orc.make_env(**env), W, H, 32, 16, want_counters=True)
+    try:
+        for g in (2, 1, 0):
+            gpu.set_option("groups", g)
+            for count in (1, 0):
+                gpu.set_option("count", count)
+                got, _ = gpu.render(cam, W, H, 32, 16)
+                st = gpu.stats()
+                gpu.set_option("count", 0)
+                assert_bitwise(got, want, "cornell, groups=%d count=%d" % (g, count))
+                if count:
+                    for k in ("samples", "rays", "scatters", "nan_retries"):
+                        assert st[k] == cnt[k], (g, k)
+        # every pixel running at once, few of them per wave: the regime the group walk is for (one shard of eight, 7 spp: no sort)
+        gpu.set_pixel_shard(5, 8, 16)
+        parts = {}
+        for g in (2, 1, 0):
+            gpu.set_option("groups", g)
+            parts[g], _ = gpu.render(cam, W, H, 7, 16)
+        gpu.set_pixel_shard(0, 1, 16)
+        assert_bitwise(parts[2], parts[0], "shard, forced group walk")
+        assert_bitwise(parts[1], parts[0], "shard, sparse-wave group walk")
+        # deep tree, full-size frame, every pixel
+        _, mats = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "dragon.json"))
+        ents = scene_io.build_entities(procedural.dragon_standin(), mats)
+        gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
+        W, H = 1920, 1080
+        cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+        imgs = {}
+        for g in (2, 1, 0):
+            gpu.set_option("groups", g)
+            imgs[g], _ = gpu.render(cam, W, H, 4, 16)
+        assert imgs[0].std() > 0.01
+        assert_bitwise(imgs[2], imgs[0], "C4 whole frame, forced group walk")
+        assert_bitwise(imgs[1], imgs[0], "C4 whole frame, sparse-wave group walk")
+    finally:
+        gpu.set_option("groups", 1)
+        gpu.set_option("count", 0)
+        gpu.set_pixel_shard(0, 1, 16)
+
+
 def test_library_communicator_single_rank(gpu, cornell):
     """The library's own RCCL path on one GPU: unique id, ncclCommInitRank(world 1), pt_render with the reduce in it, pinned
     output - bit-identical to the plain render.  (N > 1 through the same calls: tests/test_host_main.py, bench.py --gpus N.)"""

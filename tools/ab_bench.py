@@ -85,6 +85,11 @@ def main():
         cen["winddown_ray_share"] = round(cen["rays_after_death"] / max(1, cen["rays"]), 4)
         cen["winddown_time_share"] = round(cen["winddown_ticks"] / max(1, cyc["total"]), 4)
         cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
+        g = cs["groups"]
+        cen["groups"] = {"phases": g[0], "iters": g[1], "iters/phase": round(g[1] / max(1, g[0]), 2), "busy_groups/iter": round(g[2] / max(1, g[1]), 2),
+                         "node_groups/iter": round(g[3] / max(1, g[1]), 2), "leaf_groups/iter": round(g[4] / max(1, g[1]), 2), "rays": g[5],
+                         "ray_share": round(g[5] / max(1, cs["rays"]), 4), "iters/ray": round(g[2] / max(1, g[5]), 2),
+                         "cycle_share": round(g[6] / max(1, cyc["total"]), 4), "cycles/iter": round(g[6] / max(1, g[1]), 1)}
         print(json.dumps(cen))
     if opts.get("chain"):
         # per-ray turnaround of the longest sample chain: the cost pre-pass counted the rays of the first 8 samples of every pixel
