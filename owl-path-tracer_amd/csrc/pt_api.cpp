@@ -280,6 +280,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value != 0 && value != 1) return fail(c, PT_E_INVALID, "bvh_builder must be 0 (host binned SAH) or 1 (device LBVH)");
         c->bvh_builder = (int)value;
     }
+    else if (k == "wide_leaves") c->wide_leaves = value != 0; // oct nodes: subtrees of <= 7 triangles become one leaf (before pt_upload_scene)
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
@@ -394,7 +395,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_nodes = c->bvh.nodes.size();
     pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
-    pt_bvh_collapse8(c->bvh, &c->nodes8, &c->root8, &c->depth8);
+    pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8);
     if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
     { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
         const size_t n_slots = c->bvh.tris.size();

@@ -262,7 +262,7 @@ void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4,
     }
 }
 
-void pt_bvh_collapse8(const PtBvh& b, std::vector<PtNode8>* out, int32_t* root8, int* depth8)
+void pt_bvh_collapse8(const PtBvh& b, int wide_leaves, std::vector<PtNode8>* out, int32_t* root8, int* depth8)
 {
     out->clear();
     *root8 = b.root;
@@ -273,10 +273,44 @@ void pt_bvh_collapse8(const PtBvh& b, std::vector<PtNode8>* out, int32_t* root8,
         const float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
+    // Wide leaves: in the group walk lane k tests triangle k, so a subtree of <= 7 triangles that lie next to each other in leaf
+    // order is ONE leaf step (its binary levels are simply not walked).  sub[i] = {first slot, triangle count} of node i's subtree,
+    // count 0 if its triangles are not contiguous (leaf_align padding) or too many.
+    struct Range { uint32_t first, count; };
+    auto leaf_range = [](int32_t ref) { const uint32_t code = ~(uint32_t)ref; return Range{code >> 3, code & 7u}; };
+    std::vector<Range> sub(b.nodes.size(), Range{0, 0});
+    {
+        std::vector<int32_t> order; // children before parents
+        order.reserve(b.nodes.size());
+        std::vector<int32_t> st{b.root};
+        while (!st.empty()) {
+            const int32_t i = st.back();
+            st.pop_back();
+            order.push_back(i);
+            if (b.nodes[(size_t)i].left >= 0) st.push_back(b.nodes[(size_t)i].left);
+            if (b.nodes[(size_t)i].right >= 0) st.push_back(b.nodes[(size_t)i].right);
+        }
+        for (size_t k = order.size(); k-- > 0;) {
+            const PtNode& nd = b.nodes[(size_t)order[k]];
+            const Range l = nd.left >= 0 ? sub[(size_t)nd.left] : (nd.left < -1 ? leaf_range(nd.left) : Range{0, 0});
+            const Range r = nd.right >= 0 ? sub[(size_t)nd.right] : (nd.right < -1 ? leaf_range(nd.right) : Range{0, 0});
+            Range m{0, 0};
+            if (l.count && r.count && l.count + r.count <= 7u) {
+                if (l.first + l.count == r.first) m = Range{l.first, l.count + r.count};
+                else if (r.first + r.count == l.first) m = Range{r.first, l.count + r.count};
+            }
+            sub[(size_t)order[k]] = m;
+        }
+    }
+    if (wide_leaves && sub[(size_t)b.root].count) { // the whole scene is one wide leaf
+        *root8 = (int32_t)~((sub[(size_t)b.root].first << 3) | sub[(size_t)b.root].count);
+        return;
+    }
     auto child_slot = [&](const PtNode& nd, int side) {
         Slot s;
         for (int a = 0; a < 3; ++a) { s.lo[a] = nd.lo[a][side]; s.hi[a] = nd.hi[a][side]; }
         s.ref = side ? nd.right : nd.left;
+        if (wide_leaves && s.ref >= 0 && sub[(size_t)s.ref].count) s.ref = (int32_t)~((sub[(size_t)s.ref].first << 3) | sub[(size_t)s.ref].count);
         return s;
     };
     struct Item { int32_t node2; int32_t idx8; int depth; };

@@ -35,5 +35,6 @@ bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float d
 // Three-level collapse into oct nodes (PtNode8, pt_types.h): starting from the two children of a binary node, the internal slot with
 // the largest surface area is replaced by its two children until eight slots are used (or none is internal).  root8 = 0 when the
 // root is an internal node (else the binary root reference), depth8 = deepest chain of oct nodes (the group walk pushes at most
-// seven entries per level).
-void pt_bvh_collapse8(const PtBvh& bvh, std::vector<PtNode8>* out, int32_t* root8, int* depth8);
+// seven entries per level).  wide_leaves != 0: a subtree of <= 7 triangles that are contiguous in leaf order becomes one leaf
+// (lane k of a group tests triangle k).
+void pt_bvh_collapse8(const PtBvh& bvh, int wide_leaves, std::vector<PtNode8>* out, int32_t* root8, int* depth8);

@@ -997,6 +997,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 namespace {
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
 __device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ uint32_t dpp_xor3(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x1B, 0xf, 0xf, false); }  // quad_perm [3,2,1,0]
 __device__ __forceinline__ uint32_t dpp_mir8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); } // row_half_mirror
 __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
@@ -1012,8 +1013,11 @@ __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b
         hc.slot = better ? (int)s2 : hc.slot;                                                                       \
     }
 
+// park: the wave's HBM park area (as for the per-lane walk): a group phase ends as soon as a shading batch is due, the unfinished
+// groups keep their registers there and their stacks in LDS, and the next traversal phase of the wave is a group phase again
+// (n_parked > 0 on entry: resume).  Returns the number of parked lanes.
 template <bool COUNT>
-__device__ __forceinline__ void traverse_groups(const PtKernelParams& P, WaveCtx& w, int lane, uint32_t* stack0, Counters& cn)
+__device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx& w, int lane, uint32_t* stack0, uint32_t PT_AS1* park, int n_parked, Counters& cn)
 {
     const int ns = w.ns;
     uint32_t* lray = w.lray;
@@ -1028,15 +1032,33 @@ __device__ __forceinline__ void traverse_groups(const PtKernelParams& P, WaveCtx
     Hit h;
     h.t = kTMax; h.u = h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
     v3 o = vs(0.0f), d = vs(1.0f), inv = vs(1.0f);
+    if (n_parked > 0) { // resume the groups parked by the previous group phase
+        pslot = (int)park[K_PSLOT * PT_WAVE];
+        if (pslot >= 0) {
+            cur = (int)park[K_CUR * PT_WAVE];
+            sp = (int)park[K_SP * PT_WAVE];
+            h.t = __uint_as_float(park[K_BT * PT_WAVE]);
+            h.u = __uint_as_float(park[K_BU * PT_WAVE]);
+            h.v = __uint_as_float(park[K_BV * PT_WAVE]);
+            h.slot = (int)park[K_BSLOT * PT_WAVE];
+            h.id = (int)park[K_BID * PT_WAVE];
+            o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
+            d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
+            inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        }
+    }
     int n_iter = 0;
+    bool first = true;
     for (;;) {
         if (++n_iter > (1 << 22)) { // as in the per-lane walk: a corrupt reference must not spin
             if (lane == 0) gp(P.error_flag)[0] = 1u;
+            pslot = -1;
             break;
         }
         // ---- retire finished groups (the leader writes the hit over the ray origin), refill idle groups from the ray queue ----
         const bool fin = pslot >= 0 && cur == PT_DONE;
-        if (__ballot(fin) != 0ull || __ballot(pslot < 0) != 0ull) {
+        if (first || __ballot(fin) != 0ull) {
+            first = false;
             const bool fin_hit = fin && lead && h.slot >= 0, fin_miss = fin && lead && h.slot < 0;
             const unsigned long long m_fh = __ballot(fin_hit), m_fm = __ballot(fin_miss);
             if (fin_hit) {
@@ -1068,53 +1090,73 @@ __device__ __forceinline__ void traverse_groups(const PtKernelParams& P, WaveCtx
                 if (COUNT) cn.grp[5] += take;
             }
             if (__ballot(pslot >= 0) == 0ull) break; // every ray of this phase is in the hit or the miss queue
+            // a shading batch is due (the thresholds follow the wave's running pixels): park the unfinished groups and go - the
+            // idle groups get their next rays from that pass
+            if (pick_pass(w, false) != PICK_NONE) break;
         }
         // ---- one step for every group: the loads of the node groups and of the leaf groups are in flight together ----
         const bool is_node = cur >= 0, is_leaf = cur < PT_DONE;
+        const unsigned long long m_nodeg = __ballot(is_node), m_leafg = __ballot(is_leaf);
         if (COUNT) {
             cn.grp[1] += 1; cn.grp[2] += popc64(__ballot(pslot >= 0)) >> 3;
-            cn.grp[3] += popc64(__ballot(is_node)) >> 3; cn.grp[4] += popc64(__ballot(is_leaf)) >> 3;
+            cn.grp[3] += popc64(m_nodeg) >> 3; cn.grp[4] += popc64(m_leafg) >> 3;
         }
         const uint32_t code = ~(uint32_t)cur;
         const int first = (int)(code >> 3), count = is_leaf ? (int)(code & 7u) : 0;
         const bool tri_on = sub < count;
-        // unconditional loads (idle lanes read record 0): one basic block, every request in flight before the first wait
-        const size_t nb = is_node ? (size_t)(uint32_t)cur * sizeof(PtNode8) + (size_t)sub * 32 : 0;
-        const f32x4 c0 = ldg4(nodes8, nb), c1 = ldg4(nodes8, nb + 16);
-        const size_t tb = tri_on ? (size_t)(uint32_t)(first + sub) * sizeof(PtTri) : 0;
-        const f32x4 ta = ldg4(tris, tb), tb4 = ldg4(tris, tb + 16), tc = ldg4(tris, tb + 32);
-        if (COUNT && lead) { cn.nodes += is_node ? 4u : 0u; cn.tris += (uint32_t)count; } // an oct node is four 64-byte units
-        // -- node groups: lane k tests child k
-        float tn = 0.0f;
-        const int ref = __float_as_int(c1.z);
-        bool hit = false;
-        if (is_node) hit = box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
-        // entry distance with the child index in its low bits: unique within the group, ordered like the distance (tn >= kTMin > 0)
-        const uint32_t key = hit ? ((__float_as_uint(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
-        uint32_t kmin = umin_(key, dpp_xor1(key));
-        kmin = umin_(kmin, dpp_xor2(kmin));
-        kmin = umin_(kmin, dpp_mir8(kmin));
-        const bool any = kmin != 0xffffffffu;
-        const bool push = hit && key != kmin;
-        const unsigned long long m_push = __ballot(push);
-        const uint32_t pbits = (uint32_t)(m_push >> gbase) & 0xffu; // this group's pushing lanes
-        const int prank = __builtin_popcount(pbits & ((1u << sub) - 1u)), pcnt = __builtin_popcount(pbits);
-        if (push) {
-            const int e = sp + prank;
-            gstack[(e >> 3) * PT_WAVE + (e & 7)] = (uint32_t)ref;
+        // unconditional loads inside the wave-uniform branches (idle lanes read record 0): every request is in flight before the first wait
+        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0, ta = c0, tb4 = c0, tc = c0;
+        if (m_nodeg != 0ull) {
+            const size_t nb = is_node ? (size_t)(uint32_t)cur * sizeof(PtNode8) + (size_t)sub * 32 : 0;
+            c0 = ldg4(nodes8, nb); c1 = ldg4(nodes8, nb + 16);
         }
-        const int near_ref = __builtin_amdgcn_ds_bpermute((gbase | (int)(kmin & 7u)) << 2, ref);
-        // -- leaf groups: lane k tests triangle k; (t, id)-lexicographic minimum over the group, payload (u, v, slot)
-        Hit hc = h;
-        if (tri_on) tri_eval(ta, tb4, tc, first + sub, o, d, hc);
-        PT_HIT_STAGE(dpp_xor1)
-        PT_HIT_STAGE(dpp_xor2)
-        PT_HIT_STAGE(dpp_mir8)
-        h = hc; // unchanged where the group is not at a leaf: all its lanes held the same candidate
+        if (m_leafg != 0ull) {
+            const size_t tb = tri_on ? (size_t)(uint32_t)(first + sub) * sizeof(PtTri) : 0;
+            ta = ldg4(tris, tb); tb4 = ldg4(tris, tb + 16); tc = ldg4(tris, tb + 32);
+        }
+        if (COUNT && lead) { cn.nodes += is_node ? 4u : 0u; cn.tris += (uint32_t)count; } // an oct node is four 64-byte units
+        int next = PT_DONE;   // node groups with a hit child: the nearest one
+        bool descend = false;
+        if (m_nodeg != 0ull) {
+            // -- node groups: lane k tests child k
+            float tn = 0.0f;
+            const int ref = __float_as_int(c1.z);
+            bool hit = false;
+            if (is_node) hit = box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
+            // entry distance with the child index in its low bits: unique within the group, ordered like the distance (tn >= kTMin > 0)
+            const uint32_t key = hit ? ((__float_as_uint(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
+            uint32_t kmin = umin_(key, dpp_xor1(key));
+            kmin = umin_(kmin, dpp_xor2(kmin));
+            kmin = umin_(kmin, dpp_mir8(kmin));
+            descend = kmin != 0xffffffffu;
+            const bool push = hit && key != kmin;
+            // the other hit children go on the group's stack FARTHEST FIRST (the nearest of them is popped first): a pushing lane's
+            // position is the number of pushing lanes with a larger key - seven cross-lane fetches: the three other lanes of its
+            // quad, the mirror lane and the three other lanes of the mirror lane's quad
+            const uint32_t pk = push ? key : 0u;
+            const uint32_t pm = dpp_mir8(pk);
+            const int prank = (int)(dpp_xor1(pk) > key) + (int)(dpp_xor2(pk) > key) + (int)(dpp_xor3(pk) > key) + (int)(pm > key) + (int)(dpp_xor1(pm) > key) +
+                              (int)(dpp_xor2(pm) > key) + (int)(dpp_xor3(pm) > key);
+            const uint32_t pbits = (uint32_t)(__ballot(push) >> gbase) & 0xffu; // this group's pushing lanes
+            if (push) {
+                const int e = sp + prank;
+                gstack[(e >> 3) * PT_WAVE + (e & 7)] = (uint32_t)ref;
+            }
+            next = __builtin_amdgcn_ds_bpermute((gbase | (int)(kmin & 7u)) << 2, ref);
+            if (is_node) sp += __builtin_popcount(pbits);
+        }
+        if (m_leafg != 0ull) {
+            // -- leaf groups: lane k tests triangle k; (t, id)-lexicographic minimum over the group, payload (u, v, slot)
+            Hit hc = h;
+            if (tri_on) tri_eval(ta, tb4, tc, first + sub, o, d, hc);
+            PT_HIT_STAGE(dpp_xor1)
+            PT_HIT_STAGE(dpp_xor2)
+            PT_HIT_STAGE(dpp_mir8)
+            h = hc; // unchanged where the group is not at a leaf: all its lanes held the same candidate
+        }
         // -- next reference
-        if (is_node) sp += pcnt;
-        if (is_node && any) {
-            cur = near_ref;
+        if (is_node && descend) {
+            cur = next;
         } else if (is_node || is_leaf) {
             if (sp > 0) {
                 --sp;
@@ -1124,6 +1166,21 @@ __device__ __forceinline__ void traverse_groups(const PtKernelParams& P, WaveCtx
             }
         }
     }
+    // ---- park unfinished groups until the next traversal phase ----
+    const int n_left = popc64(__ballot(pslot >= 0));
+    if (n_left > 0) {
+        park[K_PSLOT * PT_WAVE] = (uint32_t)pslot;
+        if (pslot >= 0) {
+            park[K_CUR * PT_WAVE] = (uint32_t)cur;
+            park[K_SP * PT_WAVE] = (uint32_t)sp;
+            park[K_BT * PT_WAVE] = __float_as_uint(h.t);
+            park[K_BU * PT_WAVE] = __float_as_uint(h.u);
+            park[K_BV * PT_WAVE] = __float_as_uint(h.v);
+            park[K_BSLOT * PT_WAVE] = (uint32_t)h.slot;
+            park[K_BID * PT_WAVE] = (uint32_t)h.id;
+        }
+    }
+    return n_left;
 #undef LF
 #undef LFF
 }
@@ -1195,6 +1252,8 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
     w.adapt = P.tune[5] != 2; // option "adaptive" (default on; 2 = off)
     w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
     int n_parked = 0, n_rounds = 0;
+    bool parked_groups = false; // what is parked belongs to a group phase (oct nodes, group stacks): it can only be resumed by one
+    const int grp_max_rays = P.tune[6] > 0 ? P.tune[6] : PT_GROUP_MAX_RAYS, grp_max_run = P.tune[7] > 0 ? P.tune[7] : PT_GROUP_MAX_RUN; // options "tune6", "tune7"
     Counters cn;
 
     unsigned long long t_begin = 0;
@@ -1234,9 +1293,10 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
             __builtin_amdgcn_s_sleep(64);
             w.miss_blocked = false;
             if (COUNT) { cn.sched[18] += 1; cn.cyc[6] += __builtin_amdgcn_s_memtime() - t0; }
-        } else if (P.nodes8 != nullptr && n_parked == 0 && (P.groups == 2 || (w.ray_count <= PT_GROUP_MAX_RAYS && w.n_run <= PT_GROUP_MAX_RUN))) {
-            // sparse wave: eight lanes per ray (no parking: the phase ends when all its rays are in the hit / miss queues)
-            traverse_groups<COUNT>(P, w, lane, lds0, cn);
+        } else if (P.nodes8 != nullptr && (n_parked == 0 ? (P.groups == 2 || (w.ray_count <= grp_max_rays && w.n_run <= grp_max_run)) : parked_groups)) {
+            // sparse wave: eight lanes per ray; unfinished groups stay parked for the wave's next traversal phase, which is then a group phase too
+            n_parked = traverse_groups<COUNT>(P, w, lane, lds0, park, n_parked, cn);
+            parked_groups = true;
             if (COUNT) { cn.grp[0] += 1; cn.grp_cyc += __builtin_amdgcn_s_memtime() - t0; }
         } else {
             // ======================= TRAVERSAL PHASE ==============================================================
@@ -1328,7 +1388,7 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
                     if (++n_retire_passes >= 16) w.miss_blocked = false; // time to poll the waiting tickets again
                     // a full shading batch is ready: go and turn it into rays (a miss queue that only holds unpublished tickets does not count)
                     // (a sparse wave stays until its rays are done: nothing parked, so the next phase can be a group walk)
-                    if (pick_pass(w, false) != PICK_NONE && !(P.groups == 1 && w.n_run <= PT_GROUP_MAX_RUN && w.ray_count == 0)) break;
+                    if (pick_pass(w, false) != PICK_NONE && !(P.groups == 1 && w.n_run <= grp_max_run && w.ray_count == 0)) break;
                     continue;
                 }
                 // ---- one step for the majority: a BVH node step or a triangle test (thresholds 12..40 and node+triangle in
@@ -1417,6 +1477,7 @@ __global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WA
                 }
             }
             // ---- park unfinished traversals until the next traversal phase ----
+            parked_groups = false;
             n_parked = popc64(__ballot(pslot >= 0));
             if (n_parked > 0) {
                 park[K_PSLOT * PT_WAVE] = (uint32_t)pslot;
