@@ -11,8 +11,9 @@ environment (intensity 0), light from the 'areaLight' quad.  One "step" = one co
 N > 1: one process per GPU; every rank holds a scene replica and renders the pixel tiles it owns (16x16 tiles dealt
 round-robin; pixels are independent, samples of one pixel are NOT -- the reference threads one RNG stream through all
 samples of a pixel), then ONE RCCL reduce (sum) of the float3 framebuffer to rank 0 -- inside the library (pt_comm_init_rank +
-pt_render, include/mi355pt.h); torch.distributed only carries the 128-byte communicator id, the barrier and the max over ranks.
-Total work is fixed => "strong".
+pt_render, include/mi355pt.h).  torch.distributed is the CONTROL plane only and runs over gloo (CPU): the 128-byte communicator id,
+the barrier, the max over ranks and the per-rank timing table - so the only RCCL runtime in the process is the one the library
+loads (PT_RCCL_PATH overrides which).  Total work is fixed => "strong".
 
 Timed span of a step: pt_render = kernels + reduce + D2H of the complete float3 frame into pinned host memory on
 rank 0.  After the timed loop every rank checks that no watchdog fired and rank 0 checks the frame against the checksum of the
@@ -53,7 +54,7 @@ def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
     return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 GOLDEN_CRC = os.path.join(ROOT, "tests", "golden", "c4_frame_crc.json")
 
 
@@ -151,7 +152,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render path)")
     torch.cuda.set_device(local_rank)
-    D.init(backend="nccl", device=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm: barrier + max over ranks only
+    D.init(backend="gloo")  # control plane on the CPU: no second RCCL communicator next to the library's
 
     scene_io, mats, ents = build_workload()  # also loads the package
     from owl_path_tracer_amd.pyhost import binding as B
@@ -167,7 +168,6 @@ def main():
         ctx.set_option("spp_per_launch", args.spp_per_launch)
     cam = B.to_camera_data([4.0, 2.5, 0.0], [0.0, 0.75, 0.0], [0.0, 1.0, 0.0], 50.0, W, H)
 
-    dev = torch.device("cuda", local_rank)
     frame = B.PinnedFrame(W, H) if rank == 0 else None  # pinned host memory, like the reference's framebuffer (owl.hpp:108-111)
 
     def step():
@@ -180,17 +180,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # instrumented pass (untimed): work counters for the algorithmic-bytes figure
+    # instrumented passes (untimed): work counters for the algorithmic-bytes figure - of this build's walk (records as fetched: a
+    # quad node = two 64-byte units, an oct node of the sparse-wave group walk = four) and of the plain binary walk of the same tree
+    # (one 64-byte node per visit, leaves of <= 4 triangles: SURVEY 8(d)'s unit, independent of how this build packs its records)
     ctx.set_option("count", 1)
     step()
     cst = ctx.stats()
+    for k, v in (("quad", 0), ("groups", 0)):
+        ctx.set_option(k, v)
+    step()
+    cst_bin = ctx.stats()
+    for k, v in (("quad", 1), ("groups", 1)):
+        ctx.set_option(k, v)
     ctx.set_option("count", 0)
     own_pixels = int(B.shard_pixels(W, H, D.TILE, rank, world).size)
 
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms, prepass_ms, step_ms = [], [], []
+    kernel_ms, prepass_ms, step_ms, reduce_ms, d2h_ms = [], [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -199,14 +207,22 @@ def main():
         fst = ctx.stats()  # HIP events recorded on the launch stream: first launch .. end, and end of pre-pass + sort; raises if a watchdog fired
         kernel_ms.append(fst["kernel_ms"])
         prepass_ms.append(fst["prepass_ms"])
+        reduce_ms.append(fst["reduce_ms"])
+        d2h_ms.append(fst["d2h_ms"])
     fence()
     elapsed = time.perf_counter() - t0
     ctx.synchronize()  # PT_E_HIP -> PtError if any wave's watchdog fired during the timed frames: an incomplete image is not a result
     med_ms = float(np.median(step_ms))
+    # what each rank spent where (medians over the timed steps): explains a scaling curve without another run
+    mine = {"rank": rank, "pixels": own_pixels, "kernel_ms": round(float(np.median(kernel_ms)), 3), "reduce_ms": round(float(np.median(reduce_ms)), 3),
+            "d2h_ms": round(float(np.median(d2h_ms)), 3), "step_ms": round(med_ms, 3), "rays": int(cst["rays"])}
+    per_rank = [mine]
     if world > 1:
-        t = torch.tensor([elapsed, med_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, med_ms], dtype=torch.float64)  # CPU tensor: gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, med_ms = float(t[0].item()), float(t[1].item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     st = ctx.stats()
 
     crc = frame_crc(frame.rgb) if rank == 0 else None
@@ -233,6 +249,8 @@ def main():
         alg_bytes = alg_frame * main_share
         main_ms = k_ms - p_ms
         achieved = alg_bytes / (main_ms * 1e-3) / 1e9
+        alg_bin = algorithmic_bytes(cst_bin, own_pixels) * main_share  # binary-visit equivalents of the same rays
+        achieved_bin = alg_bin / (main_ms * 1e-3) / 1e9
         samples = W * H * SPP * args.steps
         out = {
             "metric": "Msamples/sec at 1920x1080x1024spp",
@@ -257,12 +275,19 @@ def main():
                        "bvh_depth": int(st["bvh_depth"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(world),
+                         "accounting": "achieved = bytes of the records this build fetches (quad node 2 x 64 B, oct node 4 x 64 B per visit, 36 B per triangle test, "
+                                       "152 B per scatter, 12 B per pixel) / duration of the main launch; *_binary_equiv = the same rays counted as a plain BVH2 walk "
+                                       "of the same tree (64 B per node visit): a figure that cannot move by repacking records",
+                         "achieved_binary_equiv": round(achieved_bin, 1), "frac_binary_equiv": round(achieved_bin / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch_binary_equiv": int(alg_bin),
+                         "counts_per_frame_rank0_binary_walk": {k: int(cst_bin[k]) for k in ("rays", "nodes", "tris", "scatters")},
                          "kernel": "pt_render_wave_kernel<false>, main launch", "kernel_ms_per_launch": round(main_ms, 3), "launches_per_step": launches,
                          "prepass_and_sort_ms": round(p_ms, 3), "kernel_ms_per_frame": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_per_frame": int(alg_frame),
                          "counts_per_frame_rank0": {k: int(cst[k]) for k in ("samples", "rays", "nodes", "tris", "scatters", "env_misses")},
                          "vgprs": st["vgprs"], "lds_bytes": st["lds_bytes"], "grid": st["grid"], "block": st["block"]},
         }
+        out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_io, mats, ents, cam.as_array())
         print(json.dumps(out), flush=True)

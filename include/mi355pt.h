@@ -92,6 +92,12 @@ typedef struct pt_stats {
     /* counted renders, group walk of sparse waves (eight lanes per ray): {phases, iterations, sum of busy groups, of groups at a
      * node, of groups at a leaf, rays traced, shader-clock cycles, 0} */
     uint64_t groups[8];
+    /* last pt_render (not pt_render_device): time on the stream between the end of the render kernels and the end of the RCCL reduce
+     * (0 without a communicator; includes waiting for the slowest rank), and of the read-back into the caller's buffers (root) */
+    double reduce_ms, d2h_ms;
+    int32_t kernel_variant; /* 1 lane per pixel, 2 wavefront kernel, 3 its fallback instance with the larger register budget (chosen when
+                             * the 128-VGPR instance of this build would need scratch, or by option "fallback") */
+    int32_t reserved;
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
@@ -145,8 +151,11 @@ int pt_synchronize(pt_ctx* ctx);
 int pt_comm_get_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
 int pt_comm_init_rank(pt_ctx* ctx, const uint8_t id[PT_COMM_ID_BYTES], int32_t rank, int32_t world_size);
 int pt_comm_destroy(pt_ctx* ctx);
-/* The reduce by itself, asynchronous on `stream` (NULL = the context's stream), in place on device buffers as filled by
- * pt_render_device (n_pixels*3 floats; d_rgba8 optional, n_pixels uint32).  A no-op without a communicator. */
+/* The reduce by itself, asynchronous on `stream` (NULL = the context's stream), in place on the device buffer pt_render_device
+ * filled (n_pixels*3 floats): exactly ONE collective on every rank, whatever else is passed.  d_rgba8 (optional, n_pixels uint32)
+ * is an OUTPUT on rank 0 - owl::make_rgba of the reduced frame, bit for bit what the owning ranks would have stored (one non-zero
+ * contributor per pixel) - and ignored on the other ranks.  A no-op without a communicator.
+ * Environment: PT_RCCL_PATH = the RCCL library to load (default librccl.so.1 by the usual search). */
 int pt_reduce_framebuffer(pt_ctx* ctx, void* d_rgb, void* d_rgba8, int64_t n_pixels, void* stream);
 /* Pinned host memory for the frame, like the reference's framebuffer (owlBufferGetPointer, owl.hpp:108-111). */
 void* pt_host_alloc(size_t bytes);
@@ -175,7 +184,13 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   "prepass_spp" (8), "cost_radius" (2: cost = maximum over the (2r+1)^2 neighbourhood), "sticky_pct" (automatic, 10-75: share of the
  *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (16: smallest of the
  *   halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
- *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build. */
+ *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build;
+ *   "groups" 1 (default: a wave with few rays to trace walks them eight lanes per ray over oct nodes) | 0 (never) | 2 (always: tests),
+ *   "wide_leaves" 1 (oct nodes: subtrees of <= 7 triangles are one leaf step; next pt_upload_scene), "tune6" / "tune7" (16 / 24: ray-queue
+ *   level and running pixels up to which a wave counts as sparse);  "coop" 0 (default) | 1: the quad nodes of all lanes are fetched
+ *   cooperatively as whole cache lines through an LDS staging area (2x the node-fetch rate, but 8 KB of LDS per wave: 9 waves per CU);
+ *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
+ *   the library does by itself when the 128-VGPR instance of a build needs scratch). */
 int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 
@@ -200,6 +215,11 @@ int pt_debug_clone_scene(pt_ctx* dst, const pt_ctx* src);
  * triangles in leaf slots, empty slots, internal slots, binary nodes, binary leaf references}.  Every leaf of the binary tree
  * must appear in exactly one quad slot; an empty slot must carry the never-hit box. */
 int pt_debug_quad_info(pt_ctx* ctx, int64_t out[8]);
+
+/* The same for the oct nodes of the group walk (PtNode8): out = {oct nodes, depth, leaf slots, triangles in leaf slots, empty slots,
+ * internal slots, largest leaf, triangle slots of the scene}.  Fails (PT_E_LIMIT) if a triangle slot is in no or in two leaves, a
+ * triangle sticks out of its leaf's box, a node is referenced twice or an empty slot has a finite box. */
+int pt_debug_oct_info(pt_ctx* ctx, int64_t out[8]);
 
 /* The pixel queue of the last pt_render* call with the cost-ordered schedule: queue_ids[i] = pixel id (x + width * y) of
  * entry i of the cost-ordered queue, input_ids[i] / cost[i] = entry i of the shard's input queue and the rays its first

@@ -21,6 +21,7 @@ extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int 
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 extern "C" int pt_debug_block(void);
+extern "C" hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream);
 extern "C" size_t pt_lbvh_workspace_bytes(int n);
 extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_size, void* d_workspace, size_t workspace_bytes, PtNode* d_nodes, uint32_t* d_order,
                                            int32_t* h_root, int32_t* h_n_nodes, int32_t* h_height, int32_t* h_max_leaf, float* h_pad, hipStream_t stream);
@@ -229,7 +230,8 @@ pt_ctx* pt_create(const pt_config* cfg)
     }
     c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evm) != hipSuccess || hipEventCreate(&c->evr) != hipSuccess ||
+        hipEventCreate(&c->evd) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "stream/event creation failed");
         delete c;
         return nullptr;
@@ -251,6 +253,8 @@ void pt_destroy(pt_ctx* c)
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         if (c->evm) (void)hipEventDestroy(c->evm);
+        if (c->evr) (void)hipEventDestroy(c->evr);
+        if (c->evd) (void)hipEventDestroy(c->evd);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -281,6 +285,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         c->bvh_builder = (int)value;
     }
     else if (k == "wide_leaves") c->wide_leaves = value != 0; // oct nodes: subtrees of <= 7 triangles become one leaf (before pt_upload_scene)
+    else if (k == "fallback") c->fallback = value != 0; // force the wavefront kernel's 168-VGPR fallback instance (tests)
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
@@ -302,6 +307,14 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     if (n_meshes < 0 || n_materials < 0 || n_textures < 0 || (n_meshes > 0 && !meshes) || (n_materials > 0 && !materials) ||
         (n_textures > 0 && !textures))
         return fail(c, PT_E_INVALID, "pt_upload_scene: null array with non-zero count");
+    // everything that can be checked without touching the context is checked first; from here on the context has NO scene until the
+    // upload has succeeded (a failure half way must not leave the previous scene's flag over new host arrays)
+    for (int i = 0; i < n_textures; ++i)
+        if (textures[i].width <= 0 || textures[i].height <= 0 || !textures[i].rgba8) return fail(c, PT_E_INVALID, "texture %d is empty", i);
+    if (material_texture)
+        for (int i = 0; i < n_materials; ++i)
+            if (material_texture[i] >= n_textures) return fail(c, PT_E_INVALID, "material %d: texture index %d out of range (%d textures)", i, material_texture[i], n_textures);
+    c->have_scene = false;
     if (!c->host_only) HIP_TRY(c, hipSetDevice(c->device));
 
     // ---- flatten entities to one record per triangle, global order = entity order then face order ----
@@ -370,17 +383,23 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         hipError_t e2 = hipMemcpy(order.data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost);
         cleanup();
         if (e1 != hipSuccess || e2 != hipSuccess) return fail(c, PT_E_HIP, "device BVH read-back failed");
-        c->bvh.root = root;
-        c->bvh.depth = height;
-        c->bvh.max_leaf = max_leaf;
-        c->bvh.pad = pad;
-        c->bvh.tris.resize((size_t)n);
-        for (int i = 0; i < n; ++i) {
-            PtTri& t = c->bvh.tris[(size_t)i];
-            std::memcpy(t.p0, &pos[(size_t)order[(size_t)i] * 9], 36);
-            t.id = (int32_t)order[(size_t)i];
-            t.material = -1;
-            t.pad = 0;
+        if (height > std::min(c->max_bvh_depth, (int)PT_MAX_STACK)) {
+            // the Karras tree has no depth control (clustered or duplicate centroids give long chains): the host builder, which
+            // caps the depth, takes over instead of failing the upload
+            pt_bvh_build(pos.data(), (int32_t)n_tris, c->leaf_size, c->max_bvh_depth, &c->bvh);
+        } else {
+            c->bvh.root = root;
+            c->bvh.depth = height;
+            c->bvh.max_leaf = max_leaf;
+            c->bvh.pad = pad;
+            c->bvh.tris.resize((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                PtTri& t = c->bvh.tris[(size_t)i];
+                std::memcpy(t.p0, &pos[(size_t)order[(size_t)i] * 9], 36);
+                t.id = (int32_t)order[(size_t)i];
+                t.material = -1;
+                t.pad = 0;
+            }
         }
     } else {
         pt_bvh_build(pos.data(), (int32_t)n_tris, c->leaf_size, c->max_bvh_depth, &c->bvh);
@@ -412,19 +431,19 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     // ---- textures, materials, environment ----
     c->textures.assign((size_t)n_textures, HostTexture{});
     for (int i = 0; i < n_textures; ++i) {
-        if (textures[i].width <= 0 || textures[i].height <= 0 || !textures[i].rgba8) return fail(c, PT_E_INVALID, "texture %d is empty", i);
         c->textures[i].w = textures[i].width;
         c->textures[i].h = textures[i].height;
         c->textures[i].px.assign(textures[i].rgba8, textures[i].rgba8 + (size_t)textures[i].width * textures[i].height);
     }
-    for (int i = 0; i < (int)c->material_texture.size(); ++i)
-        if (c->material_texture[i] >= n_textures) return fail(c, PT_E_INVALID, "material %d: texture index %d out of range (%d textures)", i, c->material_texture[i], n_textures);
     pack_materials(c, materials, n_materials);
     pt_env def{};
     copy_env(c, env ? env : &def);
+    if (!c->host_only) {
+        const int urc = pti::upload_scene_to_device(c);
+        if (urc) return urc;
+    }
     c->have_scene = true;
-    if (c->host_only) return PT_OK;
-    return pti::upload_scene_to_device(c);
+    return PT_OK;
 }
 
 } // extern "C"
@@ -573,10 +592,17 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
     int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
+    // variant of the launch: the wavefront kernel's product instance (2) unless it needs scratch in this build - then its fallback
+    // instance with the larger register budget (3): slower (12 instead of 16 waves per CU), the same arithmetic
+    int variant = c->kernel == 2 && c->fallback && !c->count ? 3 : c->kernel;
     {
-        const hipError_t ge = pt_kernel_geometry(c->kernel, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        hipError_t ge = pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        if (ge == hipErrorInvalidConfiguration && variant == 2 && !c->count) {
+            variant = 3;
+            ge = pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        }
         if (ge == hipErrorInvalidConfiguration)
-            return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
+            return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
         HIP_TRY(c, ge);
     }
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
@@ -584,7 +610,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(c->kernel, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -751,8 +777,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             }
         }
         const PtKernelParams* dP = (const PtKernelParams*)c->d_params.p + l; // one block per launch: launch l+1's copy never races launch l
-        if (c->kernel == 2) HIP_TRY(c, hipMemcpyAsync((void*)dP, &P, sizeof(PtKernelParams), hipMemcpyHostToDevice, stream));
-        HIP_TRY(c, pt_launch_render(&P, dP, c->kernel, grid, lds, stream, c->count));
+        if (c->kernel == 2) HIP_TRY(c, pt_launch_store_params(&P, (PtKernelParams*)dP, stream)); // by value: P is reused for the next launch
+        HIP_TRY(c, pt_launch_render(&P, dP, variant, grid, lds, stream, c->count));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;
@@ -763,6 +789,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     c->last_w = W;
     c->last_h = H;
     c->stats.vgprs = vg;
+    c->stats.kernel_variant = variant;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
     c->stats.block = block;
@@ -794,15 +821,26 @@ int pt_render(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int32_t max
     size_t npx = (size_t)W * H;
     if ((rc = ensure(c, c->d_out, npx * 12))) return rc;
     if (out_rgba8 && (rc = ensure(c, c->d_out8, npx * 4))) return rc;
-    rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, nullptr);
+    // with a communicator the RGBA8 image is made from the reduced float frame on the root (pt_reduce_framebuffer): every rank
+    // enqueues the same single collective whatever buffers its caller passed
+    rc = pt_render_device(c, cam, W, H, max_samples, max_depth, c->d_out.p, (out_rgba8 && !c->comm) ? c->d_out8.p : nullptr, nullptr);
     if (rc) return rc;
     // N ranks: the one collective of the path - RCCL sum-reduce of the float3 framebuffer onto rank 0 (pt_comm.cpp)
-    if (c->comm && (rc = pt_reduce_framebuffer(c, c->d_out.p, out_rgba8 ? c->d_out8.p : nullptr, (int64_t)npx, nullptr))) return rc;
+    if (c->comm && (rc = pt_reduce_framebuffer(c, c->d_out.p, (root && out_rgba8) ? c->d_out8.p : nullptr, (int64_t)npx, nullptr))) return rc;
+    HIP_TRY(c, hipEventRecord(c->evr, c->stream)); // kernels end (ev1) .. here: this rank's share of the reduce, incl. waiting for the slowest rank
     if (root) {
         HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_out.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
         if (out_rgba8) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->d_out8.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    HIP_TRY(c, hipEventRecord(c->evd, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev1, c->evr));
+        c->stats.reduce_ms = ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->evr, c->evd));
+        c->stats.d2h_ms = ms;
+    }
     return check_watchdog(c);
 }
 
@@ -908,6 +946,47 @@ int pt_debug_quad_info(pt_ctx* c, int64_t out[8])
     }
     out[0] = (int64_t)c->nodes4.size(); out[1] = c->depth4; out[2] = leaf_slots; out[3] = tris; out[4] = empty; out[5] = internal;
     out[6] = (int64_t)c->bvh.nodes.size(); out[7] = bin_leaves;
+    return PT_OK;
+}
+
+int pt_debug_oct_info(pt_ctx* c, int64_t out[8])
+{
+    if (!c || !out) return PT_E_INVALID;
+    if (!c->have_scene) return fail(c, PT_E_NO_SCENE, "pt_debug_oct_info before pt_upload_scene");
+    // {oct nodes, depth, leaf slots, triangles in leaf slots, empty slots, internal slots, largest leaf, triangle slots of the scene}
+    int64_t leaf_slots = 0, tris = 0, empty = 0, internal = 0, max_leaf = 0;
+    std::vector<uint8_t> seen(c->bvh.tris.size(), 0);
+    std::vector<uint8_t> referenced(c->nodes8.size(), 0);
+    for (const PtNode8& q : c->nodes8) {
+        for (int k = 0; k < 8; ++k) {
+            const int32_t r = q.c[k].ref;
+            if (r >= 0) {
+                if ((size_t)r >= c->nodes8.size() || referenced[(size_t)r]++) return fail(c, PT_E_LIMIT, "oct node: child %d out of range or referenced twice", r);
+                ++internal;
+            } else if (r == -1) {
+                ++empty;
+                for (int a = 0; a < 3; ++a)
+                    if (!(q.c[k].lo[a] == INFINITY && q.c[k].hi[a] == INFINITY)) return fail(c, PT_E_LIMIT, "oct node: empty slot with a finite box");
+            } else {
+                const uint32_t code = ~(uint32_t)r, first = code >> 3, count = code & 7u;
+                ++leaf_slots;
+                tris += count;
+                max_leaf = std::max<int64_t>(max_leaf, count);
+                for (uint32_t t = first; t < first + count; ++t) {
+                    if (t >= seen.size() || seen[t]++) return fail(c, PT_E_LIMIT, "oct node: triangle slot %u out of range or in two leaves", t);
+                    // the leaf's box must hold its triangles (wide leaves take the box of the subtree they replace)
+                    const PtTri& tr = c->bvh.tris[t];
+                    if (tr.id == 0x7fffffff) continue; // leaf_align padding
+                    for (int a = 0; a < 3; ++a) {
+                        const float lo = std::min(tr.p0[a], std::min(tr.p1[a], tr.p2[a])), hi = std::max(tr.p0[a], std::max(tr.p1[a], tr.p2[a]));
+                        if (lo < q.c[k].lo[a] || hi > q.c[k].hi[a]) return fail(c, PT_E_LIMIT, "oct node: triangle slot %u sticks out of its leaf box", t);
+                    }
+                }
+            }
+        }
+    }
+    out[0] = (int64_t)c->nodes8.size(); out[1] = c->depth8; out[2] = leaf_slots; out[3] = tris; out[4] = empty; out[5] = internal;
+    out[6] = max_leaf; out[7] = (int64_t)c->bvh.tris.size();
     return PT_OK;
 }
 

@@ -1,5 +1,5 @@
-// pt_comm.cpp -- the ONE collective of the render path, inside the library: an RCCL sum-reduce of the float3 framebuffer (and of
-// the optional RGBA8 image) onto rank 0 over xGMI, for both ways of driving N GPUs:
+// pt_comm.cpp -- the ONE collective of the render path, inside the library: an RCCL sum-reduce of the float3 framebuffer onto
+// rank 0 over xGMI (the optional RGBA8 image is quantised from the reduced frame on the root), for both ways of driving N GPUs:
 //   * one process per GPU (torchrun / mpirun style): pt_comm_get_unique_id on rank 0, the 128 bytes travel by whatever the
 //     launcher offers, every rank calls pt_comm_init_rank; after that pt_render() renders the rank's pixel shard, reduces, and
 //     rank 0 receives the complete frame;
@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -42,13 +43,20 @@ std::once_flag g_rccl_once;
 
 void load_rccl()
 {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
+    // PT_RCCL_PATH names the library to use (and nothing else is tried): a launcher that ships its own RCCL, or a test that wants
+    // the "RCCL unavailable" error
+    const char* forced = getenv("PT_RCCL_PATH");
+    const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string first_error;
+    for (int i = 0; i < (forced && forced[0] ? 1 : 3); ++i) {
+        const char* n = (forced && forced[0]) ? forced : defaults[i];
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.handle) break;
+        const char* e = dlerror(); // once: the call clears the error
+        if (first_error.empty()) first_error = e ? e : n;
     }
     if (!g_rccl.handle) {
-        g_rccl.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+        g_rccl.error = std::string(forced && forced[0] ? "PT_RCCL_PATH: " : "librccl.so.1 not found: ") + first_error;
         return;
     }
     struct { void** fn; const char* name; } syms[] = {
@@ -85,6 +93,8 @@ struct pt_group {
     uint32_t* pinned_rgba8 = nullptr;
     std::string err;
 };
+
+extern "C" hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long long n, hipStream_t stream);
 
 extern "C" {
 
@@ -137,9 +147,12 @@ int pt_reduce_framebuffer(pt_ctx* c, void* d_rgb, void* d_rgba8, int64_t n_pixel
     if (!c->comm) return PT_OK; // a single rank owns every pixel: nothing to add
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
-    // in place on every rank; only the root's buffer holds the sum afterwards
+    // ONE collective, in place on every rank; only the root's buffer holds the sum afterwards.  The RGBA8 image is not reduced: every
+    // pixel has exactly one non-zero contributor, so the root quantises the reduced float frame and gets bit for bit what the owning
+    // rank would have stored - and the number of collectives a rank enqueues never depends on the buffers its caller happened to pass
+    // (round 2 reduced d_rgba8 only where it was non-null: a root with an RGBA8 buffer and peers without one deadlocked).
     RCCL_TRY(c, g_rccl.Reduce(d_rgb, d_rgb, (size_t)n_pixels * 3, ncclFloat32, ncclSum, 0, (ncclComm_t)c->comm, stream));
-    if (d_rgba8) RCCL_TRY(c, g_rccl.Reduce(d_rgba8, d_rgba8, (size_t)n_pixels, ncclUint32, ncclSum, 0, (ncclComm_t)c->comm, stream));
+    if (d_rgba8 && c->comm_rank == 0) HIP_TRY(c, pt_launch_pack_rgba8((const float*)d_rgb, (uint32_t*)d_rgba8, (long long)n_pixels, stream));
     return PT_OK;
 }
 
@@ -270,36 +283,59 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t W, int32_t H, int
         if (!g->pinned_rgb || !g->pinned_rgba8) return bad(g->ctx[0], pti::fail(g->ctx[0], PT_E_HIP, "pinned host framebuffer allocation failed"));
         g->cap_px = npx;
     }
-    // every device renders its own tiles (asynchronous launches, one stream per device) ...
+    // on any failure below: remember the reason in the group, drain every device's stream (launches of the other devices may be in
+    // flight), then return
+    auto fail_all = [&](pt_ctx* c, int rc) {
+        g->err = pt_last_error(c);
+        for (pt_ctx* o : g->ctx) {
+            (void)hipSetDevice(o->device);
+            (void)hipStreamSynchronize(o->stream);
+        }
+        return rc;
+    };
+    // every device renders its own tiles (asynchronous launches, one stream per device); the RGBA8 image is made on device 0 from
+    // the reduced float frame ...
     for (int i = 0; i < n; ++i) {
         pt_ctx* c = g->ctx[(size_t)i];
-        int rc = pt_render_device(c, cam, W, H, max_samples, max_depth, g->d_rgb[(size_t)i], out_rgba8 ? g->d_rgba8[(size_t)i] : nullptr, nullptr);
-        if (rc) return bad(c, rc);
+        int rc = pt_render_device(c, cam, W, H, max_samples, max_depth, g->d_rgb[(size_t)i], (out_rgba8 && n == 1) ? g->d_rgba8[(size_t)i] : nullptr, nullptr);
+        if (rc) return fail_all(c, rc);
     }
-    // ... then ONE reduce per buffer onto device 0 (grouped: one host thread drives all ranks of the communicator)
-    if (n > 1) {
-        pt_ctx* c0 = g->ctx[0];
-        RCCL_TRY(c0, g_rccl.GroupStart());
-        for (int i = 0; i < n; ++i) {
-            pt_ctx* c = g->ctx[(size_t)i];
-            ncclResult_t r = g_rccl.Reduce(g->d_rgb[(size_t)i], g->d_rgb[(size_t)i], npx * 3, ncclFloat32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
-            if (r == ncclSuccess && out_rgba8)
-                r = g_rccl.Reduce(g->d_rgba8[(size_t)i], g->d_rgba8[(size_t)i], npx, ncclUint32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
-            if (r != ncclSuccess) {
-                (void)g_rccl.GroupEnd();
-                return bad(c, pti::fail(c, PT_E_HIP, "ncclReduce failed: %s", g_rccl.GetErrorString(r)));
-            }
-        }
-        RCCL_TRY(c0, g_rccl.GroupEnd());
-    }
+    // ... then ONE reduce onto device 0 (grouped: one host thread drives all ranks of the communicator)
     pt_ctx* c0 = g->ctx[0];
-    if (hipSetDevice(c0->device) != hipSuccess) return bad(c0, pti::fail(c0, PT_E_HIP, "hipSetDevice(%d) failed", c0->device));
+    if (n > 1) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return fail_all(c0, pti::fail(c0, PT_E_HIP, "ncclGroupStart failed: %s", g_rccl.GetErrorString(r)));
+        pt_ctx* bad_ctx = nullptr;
+        for (int i = 0; i < n && r == ncclSuccess; ++i) {
+            pt_ctx* c = g->ctx[(size_t)i];
+            r = g_rccl.Reduce(g->d_rgb[(size_t)i], g->d_rgb[(size_t)i], npx * 3, ncclFloat32, ncclSum, 0, (ncclComm_t)c->comm, c->stream);
+            if (r != ncclSuccess) bad_ctx = c;
+        }
+        // the group is closed even after a failed call (an open group would swallow every later call of this thread); a reduce that
+        // only some ranks joined cannot complete, which the drain in fail_all would wait for: the communicator is unusable after such
+        // an error and the message says so
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r != ncclSuccess) {
+            g->err = std::string("ncclReduce failed on device ") + std::to_string(bad_ctx->device) + ": " + g_rccl.GetErrorString(r) + " (destroy the group)";
+            (void)pti::fail(bad_ctx, PT_E_HIP, "%s", g->err.c_str());
+            return PT_E_HIP;
+        }
+        if (re != ncclSuccess) return fail_all(c0, pti::fail(c0, PT_E_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(re)));
+    }
+    if (hipSetDevice(c0->device) != hipSuccess) return fail_all(c0, pti::fail(c0, PT_E_HIP, "hipSetDevice(%d) failed", c0->device));
+    if (out_rgba8 && n > 1 && pt_launch_pack_rgba8((const float*)g->d_rgb[0], (uint32_t*)g->d_rgba8[0], (long long)npx, c0->stream) != hipSuccess)
+        return fail_all(c0, pti::fail(c0, PT_E_HIP, "RGBA8 pack launch failed"));
     if (hipMemcpyAsync(g->pinned_rgb, g->d_rgb[0], npx * 12, hipMemcpyDeviceToHost, c0->stream) != hipSuccess ||
         (out_rgba8 && hipMemcpyAsync(g->pinned_rgba8, g->d_rgba8[0], npx * 4, hipMemcpyDeviceToHost, c0->stream) != hipSuccess))
-        return bad(c0, pti::fail(c0, PT_E_HIP, "framebuffer read-back failed"));
-    for (int i = 0; i < n; ++i) { // drains every device's stream and reads its watchdog flag
-        int rc = pt_synchronize(g->ctx[(size_t)i]);
-        if (rc) return bad(g->ctx[(size_t)i], rc);
+        return fail_all(c0, pti::fail(c0, PT_E_HIP, "framebuffer read-back failed"));
+    {
+        int first_rc = PT_OK;
+        pt_ctx* first_bad = nullptr;
+        for (int i = 0; i < n; ++i) { // drains EVERY device's stream and reads its watchdog flag
+            const int rc = pt_synchronize(g->ctx[(size_t)i]);
+            if (rc && !first_rc) { first_rc = rc; first_bad = g->ctx[(size_t)i]; }
+        }
+        if (first_rc) return bad(first_bad, first_rc);
     }
     std::memcpy(out_rgb, g->pinned_rgb, npx * 12);
     if (out_rgba8) std::memcpy(out_rgba8, g->pinned_rgba8, npx * 4);

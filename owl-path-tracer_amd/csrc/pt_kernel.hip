@@ -1201,8 +1201,17 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
 // The instrumented instance gets 256 VGPRs (2 waves/SIMD): with 128 it spills ~50 registers to scratch, and a spilling build of this
 // kernel rendered wrong pixels in round 1 (both instrumented instances, identical source otherwise; never the 128-VGPR product
 // instance, which does not spill).  pt_render refuses to launch any instance that needs scratch (pt_kernel_geometry).
-template <bool COUNT>
-__global__ void __launch_bounds__(PT_WAVE, COUNT ? PT_COUNT_WAVES_PER_EU : PT_WAVES_PER_EU) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
+// Instances (WAVES = minimum waves per SIMD the register allocator must allow = 512 / VGPR budget):
+//   <false, PT_WAVES_PER_EU = 4>   the product instance: 128 VGPRs, 16 waves per CU;
+//   <false, PT_FALLBACK_WAVES = 3> the same source with a 168-VGPR budget (12 waves per CU): chosen automatically when the 128-VGPR
+//                                  instance of THIS build needs scratch (a compiler bump, a local edit) - slower, still exact,
+//                                  instead of refusing to render (pt_kernel_geometry; option "fallback" forces it);
+//   <true, PT_COUNT_WAVES_PER_EU = 2> the instrumented instance.
+#ifndef PT_FALLBACK_WAVES
+#define PT_FALLBACK_WAVES 3
+#endif
+template <bool COUNT, int WAVES>
+__global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
 {
     // The parameter block lives in HBM and is read with scalar loads where it is used.  Passed by value it arrives as
     // s_load_dwordx16 tuples that stay live for the whole kernel; the register allocator then spilled them to VGPR lanes
@@ -1683,6 +1692,33 @@ extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int 
     return hipGetLastError();
 }
 
+// RGBA8 image of a float3 framebuffer (device.cu:252-253 applied to a whole frame).  With N ranks only the float3 frame is reduced
+// (one collective, the same on every rank whatever buffers its caller passed); the root quantises the reduced frame here - every
+// pixel has one non-zero contributor, so this is bit for bit what the owning rank's kernel would have stored.
+__global__ void __launch_bounds__(256) pt_pack_rgba8_kernel(const float* __restrict__ rgb, uint32_t* __restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = make_rgba(V(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]));
+}
+
+extern "C" hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_pack_rgba8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rgb, out, n);
+    return hipGetLastError();
+}
+
+// The parameter block of a wavefront launch, stored by a one-thread kernel: kernel arguments are captured when the launch is
+// enqueued, so the host copy may be reused for the next launch at once (a hipMemcpyAsync from pageable memory is only safe while the
+// runtime stages it at enqueue time).
+__global__ void pt_store_params_kernel(const PtKernelParams p, PtKernelParams* __restrict__ dst) { *dst = p; }
+
+extern "C" hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_store_params_kernel, dim3(1), dim3(1), 0, stream, *p, d_dst);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
                                        hipStream_t stream, int count)
 {
@@ -1690,8 +1726,9 @@ extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelPa
         if (count) hipLaunchKernelGGL(pt_render_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds_bytes, stream, *p);
         else hipLaunchKernelGGL(pt_render_kernel<false>, dim3(grid), dim3(PT_BLOCK), lds_bytes, stream, *p);
     } else {
-        if (count) hipLaunchKernelGGL(pt_render_wave_kernel<true>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
-        else hipLaunchKernelGGL(pt_render_wave_kernel<false>, dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+        if (count) hipLaunchKernelGGL((pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+        else if (variant == 3) hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_FALLBACK_WAVES>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+        else hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_WAVES_PER_EU>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
     }
     return hipGetLastError();
 }
@@ -1705,8 +1742,9 @@ extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const flo
     return hipGetLastError();
 }
 
-// Launch geometry of a render variant: block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for
-// the wavefront kernel), per-block global state words, registers, occupancy.
+// Launch geometry of a render variant (1: lane per pixel, 2: wavefront kernel, 3: the wavefront kernel's 168-VGPR fallback
+// instance): block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for the wavefront kernel), per-block
+// global state words, registers, occupancy.  hipErrorInvalidConfiguration: the instance needs scratch (see below).
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels)
 {
@@ -1719,7 +1757,8 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         *ns = PT_BLOCK;
         *state_words_per_block = 0;
     } else {
-        fn = count ? (const void*)pt_render_wave_kernel<true> : (const void*)pt_render_wave_kernel<false>;
+        fn = count ? (const void*)pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU>
+                   : (variant == 3 ? (const void*)pt_render_wave_kernel<false, PT_FALLBACK_WAVES> : (const void*)pt_render_wave_kernel<false, PT_WAVES_PER_EU>);
         int n = want_ns < 16 ? 16 : (want_ns > 255 ? 255 : want_ns);
         *block = PT_WAVE;
         *ns = n;

@@ -4,7 +4,7 @@
 // <scene>_<test.name>_<attribute_name>(<value>).png in the CWD.  The render itself goes through the C-ABI (mi355pt.h).
 //
 // Optional flags (defaults reproduce the reference, which has no CLI): --assets DIR, --out DIR, --settings FILE, --device N
-// (-1: load + build only, no render), --gpus N (devices 0..N-1 of this node: pixel tiles sharded over them, one RCCL reduce of the
+// (-1: load + build only, no render), --gpus N (devices --device .. --device + N - 1 of this node, default 0..N-1: pixel tiles sharded over them, one RCCL reduce of the
 // float3 framebuffer onto device 0 - pt_group_* in mi355pt.h; the image is bit-identical to --gpus 1), --dump-scene FILE (binary
 // dump of the ingested scene for the loader tests).
 #include <sys/stat.h>
@@ -222,8 +222,10 @@ int main(int argc, char** argv)
 
         if (gpus < 0) throw std::runtime_error("--gpus needs a positive count");
         if (meshes.empty()) throw std::runtime_error("no geometries"); // application.cpp:133
-        if (gpus >= 1 && device >= 0) { // devices 0..gpus-1: a scene replica on each, the library's communicator across them
-            a.group = pt_group_create(nullptr, gpus);
+        if (gpus >= 1 && device >= 0) { // devices device..device+gpus-1: a scene replica on each, the library's communicator across them
+            std::vector<int32_t> devs((size_t)gpus);
+            for (int i = 0; i < gpus; ++i) devs[(size_t)i] = device + i;
+            a.group = pt_group_create(devs.data(), gpus);
             if (!a.group) throw std::runtime_error(std::string("pt_group_create: ") + pt_last_error(nullptr));
             a.ctx = pt_group_ctx(a.group, 0);
             check(a, pt_group_upload_scene(a.group, meshes.data(), (int32_t)meshes.size(), a.materials.data(), (int32_t)a.scene.materials.size(),

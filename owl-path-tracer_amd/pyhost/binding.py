@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("block", C.c_int32), ("grid", C.c_int32), ("stack_entries", C.c_int32),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("scatters", C.c_uint64),
                 ("env_misses", C.c_uint64), ("nan_retries", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8)]
+                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8), ("reduce_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_variant", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -65,7 +65,7 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upl
            "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_framebuffer", "pt_host_alloc", "pt_host_free",
            "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_ctx", "pt_group_last_error", "pt_group_upload_scene",
-           "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info", "pt_debug_clone_scene"]
+           "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info", "pt_debug_oct_info", "pt_debug_clone_scene"]
 PT_COMM_ID_BYTES = 128
 
 _lib = None
@@ -129,6 +129,7 @@ def lib():
     L.pt_group_set_materials.argtypes = [C.c_void_p, fp, C.c_int32]
     L.pt_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.pt_debug_quad_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.pt_debug_oct_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.pt_debug_clone_scene.argtypes = [C.c_void_p, C.c_void_p]
     L.pt_group_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_uint32)]
     _lib = L
@@ -325,6 +326,11 @@ class Context:
         a = (C.c_int64 * 8)()
         self._check(lib().pt_debug_quad_info(self._h, a), "pt_debug_quad_info")
         return dict(zip(("quad_nodes", "depth", "leaf_slots", "triangles", "empty_slots", "internal_slots", "binary_nodes", "binary_leaf_refs"), [int(x) for x in a]))
+
+    def oct_info(self):
+        a = (C.c_int64 * 8)()
+        self._check(lib().pt_debug_oct_info(self._h, a), "pt_debug_oct_info")
+        return dict(zip(("oct_nodes", "depth", "leaf_slots", "triangles", "empty_slots", "internal_slots", "largest_leaf", "triangle_slots"), [int(x) for x in a]))
 
     def read_queue(self, cap):
         """(queue_ids, input_ids, cost) of the last cost-ordered render (empty arrays if it did not sort)."""

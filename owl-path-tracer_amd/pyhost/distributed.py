@@ -6,7 +6,8 @@ device.cu:229-243), so the frame is sharded by pixel tile, never by sample.  Eve
 `pt_shard_pixels(W, H, tile, rank, world)` into a zero-initialised W*H*3 float buffer; because every pixel has exactly one
 non-zero contributor the sum over ranks is exact, i.e. the N-GPU image is bit-identical to the 1-GPU image.
 On the GPU the reduce is the LIBRARY's (pt_comm_init_rank + pt_render / pt_group_render: RCCL inside libmi355pt.so, pt_comm.cpp);
-bench.py uses torch.distributed only for the rendezvous (the 128-byte communicator id), the barrier and the max over ranks.
+bench.py uses torch.distributed - over gloo, on the CPU - only for the rendezvous (the 128-byte communicator id), the barrier, the
+max over ranks and the per-rank timing table: the library's RCCL communicator is the only one in the process.
 `reduce_framebuffer` below is the same sum over gloo for the CPU tests of the sharding logic (tests/test_multi_rank_cpu.py), where
 no GPU and therefore no RCCL exists.
 """
@@ -28,12 +29,7 @@ def init(backend=None, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kw = {}
-        if backend == "nccl" and device is not None:
-            kw["device_id"] = device
-        dist.init_process_group(backend, **kw)
+        dist.init_process_group(backend or "gloo")
     return rank, local_rank, world
 
 

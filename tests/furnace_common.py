@@ -1,5 +1,5 @@
 """Furnace known-answer shared by the CPU (oracle) and GPU (HIP path) tests: the four reference-rendered furnace images whose
-material is unambiguous (tests/golden/furnace_reference.json, built by tests/golden/make_furnace_fixture.py from
+material is unambiguous - and, round 3, the centre of a fifth that pins the ROUGH GGX lobe - (tests/golden/furnace_reference.json, built by tests/golden/make_furnace_fixture.py from
 thesis/assets/furnace-test/*.png of the reference) against our render of the same setup.
 
 The reference's sphere geometry is a missing blob (assets/sphere.obj.scene); only its silhouette is known from the images
@@ -46,6 +46,14 @@ def check(key, rgba8):
     inside = rr < 0.97
     if ref["min"] == 255.0:  # diffuse_roughness(1.0): the reference image is 255 everywhere
         assert (g == 255).all(), "%s: %d pixels below 255" % (key, int((g < 255).sum()))
+        return rings
+    if "pinned_rings" in ref:
+        # metallic_vndf_roughness(1.0): rendered by the thesis' VNDF-SAMPLED variant of the rough GGX lobe; the shipped lobe (NDF-sampled,
+        # VNDF pdf) must agree with it only at normal incidence (tests/golden/make_furnace_fixture.py has the argument), i.e. in the
+        # centre rings.  This pins D_GTR2, G2, lambda and the Fresnel term at alpha = 1 with reference-rendered data.
+        for k in ref["pinned_rings"]:
+            assert abs(rings[k] - ref["ring_means"][k]) <= 1.0, (key, k, rings[k], ref["ring_means"][k])
+        assert rings[-1] < ref["ring_means"][-1]  # and the rim is darker than the VNDF-sampled image, as the weights predict
         return rings
     assert np.abs(np.array(rings) - np.array(ref["ring_means"])).max() <= 1.0, (key, rings, ref["ring_means"])
     if ref["fraction_255"] > 0.99:  # mirror-like: saturated except at the very rim

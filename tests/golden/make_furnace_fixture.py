@@ -9,10 +9,11 @@ albedo E[f |cos| / pdf] of the material at that pixel's viewing angle, which dep
 silhouette centre.  The fixture therefore stores, per image, the mean 8-bit value in ten rings of normalised radius plus the
 centre statistics - data, a few hundred bytes; the PNGs themselves stay in the reference.
 
-Only the images whose material is unambiguous from the file name AND the shipped source are used: `diffuse` (sphere.json as
-shipped, roughness 0 / 1), `metallic` (metallic 1, roughness 0) and `specular_transmission` (transmission 1, roughness 0).  The
+Only the images whose material is unambiguous from the file name AND the shipped source are used in full: `diffuse` (sphere.json
+as shipped, roughness 0 / 1), `metallic` (metallic 1, roughness 0) and `specular_transmission` (transmission 1, roughness 0).  The
 `metallic_ndf` / `metallic_vndf` / `coupled` / `uncoupled` images document alternative code states the thesis compares (the
-shipped specular lobe samples the NDF but uses the VNDF pdf, disney_specular.cuh:144,157) and match none of them exactly.
+shipped specular lobe samples the NDF but uses the VNDF pdf, disney_specular.cuh:144,157) and match none of them exactly - except
+where the variants provably coincide: the CENTRE of `metallic_vndf_roughness(1.0)` (normal incidence), see USE below.
 
 Run in the build container (needs /root/reference): python tests/golden/make_furnace_fixture.py
 """
@@ -26,7 +27,16 @@ SRC = "/root/reference/thesis/assets/furnace-test"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "furnace_reference.json")
 USE = {"diffuse_roughness(0.0)": dict(roughness=0.0), "diffuse_roughness(1.0)": dict(roughness=1.0),
        "metallic_roughness(0.0)": dict(metallic=1.0, roughness=0.0),
-       "specular_transmission_roughness(0.0)": dict(specular_transmission=1.0, roughness=0.0, specular_transmission_roughness=0.0)}
+       "specular_transmission_roughness(0.0)": dict(specular_transmission=1.0, roughness=0.0, specular_transmission_roughness=0.0),
+       # Round 3: the ROUGH GGX lobe, pinned where the thesis variant and the shipped code must agree.  The image was rendered with the
+       # VNDF-sampled variant (sample_gtr2_vndf, disney_specular.cuh:85-110, unused in the shipped code); the shipped lobe samples the
+       # full NDF and divides by the VNDF pdf (:144,:157).  Both estimate the same integrand f |cos| = D G2 F / (4 cos_o) with weights
+       # that differ by D_vis(h) / D(h) cos_h ... = G1(wo) max(0, wo.h) / (wo.z wh.z); at NORMAL incidence wo = n: G1(wo) = 1 and
+       # wo.h = wh.z, so the ratio is 1 and the two estimators coincide sample by sample in expectation.  Only the rings of
+       # normalised radius < 0.2 (viewing angle < 11.5 degrees off the normal) are compared: `pinned_rings`.  Towards the rim the
+       # NDF-sampled / VNDF-weighted estimator of the shipped code is darker (measured: 93.5 vs 132.1 in the outermost ring).
+       "metallic_vndf_roughness(1.0)": dict(metallic=1.0, roughness=1.0)}
+PINNED_RINGS = {"metallic_vndf_roughness(1.0)": [0, 1]}
 
 
 def main():
@@ -46,6 +56,8 @@ def main():
         c = g[H // 2 - 20:H // 2 + 20, W // 2 - 20:W // 2 + 20]
         out["images"][key] = {"material_overrides": mat, "size": [W, H], "ring_means": rings, "centre_mean": float(c.mean()), "centre_std": float(c.std()),
                               "min": float(g.min()), "fraction_255": float((g == 255).mean())}
+        if key in PINNED_RINGS:
+            out["images"][key]["pinned_rings"] = PINNED_RINGS[key]
     out["silhouette_half_height_px"] = sil
     out["silhouette_radius_over_half_image"] = sil / 512.0
     with open(OUT, "w") as f:

@@ -146,3 +146,52 @@ def test_quad_nodes_cover_the_binary_tree(cornell, leaf):
     assert q["leaf_slots"] + q["internal_slots"] + q["empty_slots"] == 4 * q["quad_nodes"]
     assert 0 < q["quad_nodes"] < q["binary_nodes"] and 0 < q["depth"] <= (ctx.stats()["bvh_depth"] + 1) // 2 + 1
     ctx.close()
+
+
+@pytest.mark.parametrize("leaf,wide", [(1, 1), (4, 1), (4, 0), (7, 1)])
+def test_oct_nodes_cover_the_binary_tree(cornell, leaf, wide):
+    """The three-level collapse the group walk reads (PtNode8, round 3): every triangle slot sits in exactly one leaf and inside that
+    leaf's box (pt_debug_oct_info fails otherwise), every oct node but the root is referenced once, slots add up, and wide leaves
+    (subtrees of <= 7 contiguous triangles as one leaf) never exceed the 3-bit count."""
+    ctx = B.Context(-1)
+    ctx.set_option("leaf_size", leaf)
+    ctx.set_option("wide_leaves", wide)
+    ctx.upload_scene(cornell["entities"], [m for _, m, _ in cornell["materials"]])
+    o, q = ctx.oct_info(), ctx.quad_info()
+    n_tris = cornell["flat"]["positions"].reshape(-1, 9).shape[0]
+    assert o["triangles"] == n_tris == o["triangle_slots"]
+    assert o["internal_slots"] == o["oct_nodes"] - 1
+    assert o["leaf_slots"] + o["internal_slots"] + o["empty_slots"] == 8 * o["oct_nodes"]
+    assert 0 < o["oct_nodes"] < q["quad_nodes"] and 0 < o["depth"] <= q["depth"]
+    assert o["largest_leaf"] <= 7
+    if wide:
+        assert o["leaf_slots"] < q["binary_leaf_refs"] or leaf == 7  # leaves were merged
+    else:
+        assert o["leaf_slots"] == q["binary_leaf_refs"] and o["largest_leaf"] <= leaf
+    ctx.close()
+
+
+def test_rccl_load_failure_is_an_error_code_not_a_crash(tmp_path):
+    """Round-2 advisor finding: a box without librccl crashed in the error path (dlerror() called twice, NULL into std::string).
+    PT_RCCL_PATH forces the load to fail; the communicator calls must return PT_E_HIP with a message."""
+    import subprocess, sys, os
+    from conftest import ROOT
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import ptamd; ptamd.load()\n"
+        "from owl_path_tracer_amd.pyhost import binding as B\n"
+        "import ctypes as C\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = B.lib().pt_comm_get_unique_id(buf)\n"
+        "msg = B.lib().pt_last_error(None).decode()\n"
+        "assert rc == -5 or rc < 0, rc\n"
+        "assert 'RCCL unavailable' in msg and 'no_such_rccl' in msg, msg\n"
+        "rc2 = B.lib().pt_comm_get_unique_id(buf)\n"
+        "assert rc2 == rc\n"
+        "print('OK', rc, msg)\n" % ROOT
+    )
+    env = dict(os.environ, PT_RCCL_PATH=str(tmp_path / "no_such_rccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

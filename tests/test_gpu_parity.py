@@ -598,6 +598,64 @@ def test_group_walk_bitwise(gpu, orc, cornell, scene_io, procedural):
         gpu.set_pixel_shard(0, 1, 16)
 
 
+def test_vgpr_fallback_instance(gpu, orc, cube, scene_io):
+    """The wavefront kernel's second instance (168-VGPR budget, 12 waves per CU) is what the library launches when the 128-VGPR
+    instance of a build would need scratch; option "fallback" forces it.  Same source, same arithmetic: C1 bit for bit."""
+    tex = scene_io.checker_texture()
+    env = B.make_env(use_auto=True, intensity=1.0)
+    _upload(gpu, cube, textures=[tex], mesh_textures=[0], env=env)
+    W = H = 256
+    cam = _cam(cube, W, H)
+    S = orc.Scene(cube["flat"])
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 4)
+    gpu.set_option("fallback", 1)
+    try:
+        got, _ = gpu.render(cam, W, H, 16, 4)
+        st = gpu.stats()
+    finally:
+        gpu.set_option("fallback", 0)
+    assert st["kernel_variant"] == 3 and 128 < st["vgprs"] <= 168, (st["kernel_variant"], st["vgprs"])
+    assert_bitwise(got, want, "C1 through the fallback instance")
+    got, _ = gpu.render(cam, W, H, 16, 4)
+    assert gpu.stats()["kernel_variant"] == 2 and gpu.stats()["vgprs"] <= 128
+
+
+def test_vgpr_fallback_build():
+    """A build whose product instance DOES spill (libmi355pt_spilltest.so: -DPT_WAVES_PER_EU=5, 96 VGPRs + scratch): pt_render must
+    pick the fallback instance by itself instead of refusing (round 2: PT_E_LIMIT for every user after a compiler bump), and C1 must
+    come out bit for bit.  Runs in a child process because the library path is fixed at import."""
+    import subprocess, sys
+    from conftest import ROOT
+
+    lib = os.path.join(ROOT, "owl-path-tracer_amd", "libmi355pt_spilltest.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmi355pt_spilltest.so not built (make -C owl-path-tracer_amd/csrc spilltest)")
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import ptamd; ptamd.load()
+from owl_path_tracer_amd.pyhost import binding as B, scene_io
+import oracle as orc
+assert B.LIB_PATH.endswith("libmi355pt_spilltest.so"), B.LIB_PATH
+sc = scene_io.load_scene_dir(os.path.join(%(root)r, "assets"), "cube")
+tex = scene_io.checker_texture()
+ctx = B.Context(0)
+ctx.upload_scene(sc["entities"], [m for _, m, _ in sc["materials"]], textures=[tex], mesh_textures=[0], env=B.make_env(use_auto=True, intensity=1.0))
+W = H = 256
+c = sc["camera"]
+cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+got, _ = ctx.render(cam, W, H, 16, 4)
+st = ctx.stats()
+assert st["kernel_variant"] == 3 and 128 < st["vgprs"] <= 168, (st["kernel_variant"], st["vgprs"])
+flat = scene_io.flatten_scene(sc["entities"], sc["materials"], {0: tex})
+want, _, _ = orc.Scene(flat).render(orc.camera_from_array(cam.as_array()), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 4)
+assert (got.view(np.uint32) == want.view(np.uint32)).all(), int((got.view(np.uint32) != want.view(np.uint32)).sum())
+print("FALLBACK_OK", st["vgprs"])
+""" % dict(root=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PT_LIB_PATH=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_library_communicator_single_rank(gpu, cornell):
     """The library's own RCCL path on one GPU: unique id, ncclCommInitRank(world 1), pt_render with the reduce in it, pinned
     output - bit-identical to the plain render.  (N > 1 through the same calls: tests/test_host_main.py, bench.py --gpus N.)"""
@@ -621,7 +679,7 @@ def test_library_communicator_single_rank(gpu, cornell):
         ctx.close()
 
 
-@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)"])
+@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)", "metallic_vndf_roughness(1.0)"])
 def test_furnace_against_reference_rendered_images_gpu(gpu, orc, scene_io, procedural, key):
     """The HIP path against the reference-rendered furnace images (tests/furnace_common.py; tests/test_oracle_render.py holds the
     same check for the oracle) and, bit for bit, against the oracle on the same frame."""

@@ -53,15 +53,23 @@ def _device_count():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_library_reduce_across_processes(tmp_path, world):
+    """The root asks for the RGBA8 image, the other ranks pass no buffers at all: every rank must still enqueue the same collectives
+    (round-2 advisor finding: the RGBA8 reduce was issued only where a buffer was passed).  World 1 runs on the one-GPU boxes."""
     if _device_count() < world:
         pytest.skip("needs %d GPUs" % world)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT), str(r), str(world), str(tmp_path)], env=env) for r in range(world)]
     t0 = time.time()
-    for p in procs:
-        p.wait(timeout=max(1.0, 600 - (time.time() - t0)))
+    try:
+        for p in procs:
+            p.wait(timeout=max(1.0, 600 - (time.time() - t0)))
+    finally:  # a rank that hangs in a collective must not outlive the test holding a GPU
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
     sys.path.insert(0, ROOT)
     from owl_path_tracer_amd.pyhost import binding as B, scene_io

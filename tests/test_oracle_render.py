@@ -176,7 +176,7 @@ def test_golden_regression(orc, cube):
     np.testing.assert_array_equal(rgb, np.load(path))
 
 
-@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)"])
+@pytest.mark.parametrize("key", ["diffuse_roughness(0.0)", "diffuse_roughness(1.0)", "metallic_roughness(0.0)", "specular_transmission_roughness(0.0)", "metallic_vndf_roughness(1.0)"])
 def test_furnace_against_reference_rendered_images(orc, scene_io, procedural, key):
     """The oracle against the ONLY rendered outputs the reference repository holds (thesis/assets/furnace-test): radial profile of
     the 8-bit image, ring by ring (tests/furnace_common.py).  This pins, with data produced by the reference itself: the camera, the
