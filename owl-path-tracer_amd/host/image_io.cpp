@@ -231,13 +231,16 @@ Image load_png_rgba8(const std::string& path)
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
     while (p + 8 <= d.size()) {
-        uint32_t len = (d[p] << 24) | (d[p + 1] << 16) | (d[p + 2] << 8) | d[p + 3];
+        const uint32_t len = ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | d[p + 3];
         std::string type(d.begin() + p + 4, d.begin() + p + 8);
         const uint8_t* body = d.data() + p + 8;
         if (p + 12 + len > d.size()) throw std::runtime_error(path + ": truncated chunk");
         if (type == "IHDR") {
-            w = (body[0] << 24) | (body[1] << 16) | (body[2] << 8) | body[3];
-            h = (body[4] << 24) | (body[5] << 16) | (body[6] << 8) | body[7];
+            if (len < 13) throw std::runtime_error(path + ": short IHDR");
+            const uint32_t uw = ((uint32_t)body[0] << 24) | ((uint32_t)body[1] << 16) | ((uint32_t)body[2] << 8) | body[3];
+            const uint32_t uh = ((uint32_t)body[4] << 24) | ((uint32_t)body[5] << 16) | ((uint32_t)body[6] << 8) | body[7];
+            if (uw == 0 || uh == 0 || uw > 65535u || uh > 65535u) throw std::runtime_error(path + ": image size out of range (1..65535 per side)");
+            w = (int)uw; h = (int)uh;
             depth = body[8]; ctype = body[9]; interlace = body[12];
         } else if (type == "IDAT") idat.insert(idat.end(), body, body + len);
         else if (type == "PLTE") plte.assign(body, body + len);
@@ -322,6 +325,9 @@ Image load_hdr_as_ldr_rgba8(const std::string& path)
     std::string res = line();
     int h = 0, w = 0;
     if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) throw std::runtime_error(path + ": unsupported HDR orientation");
+    if (w > 65535 || h > 65535) throw std::runtime_error(path + ": image size out of range (1..65535 per side)");
+    // before anything is allocated: every scanline takes at least 4 bytes of the file (an RLE scanline header; a flat one 4 * w)
+    if (p > d.size() || (size_t)h * 4 > d.size() - p) throw std::runtime_error(path + ": truncated pixel data");
     std::vector<uint8_t> rgbe((size_t)w * h * 4);
     for (int y = 0; y < h; ++y) {
         uint8_t* row = &rgbe[(size_t)y * w * 4];
