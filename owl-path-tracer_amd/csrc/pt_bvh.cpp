@@ -422,6 +422,77 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
     }
 }
 
+bool pt_bvh_from_hierarchy(const float* positions, int32_t n_tris, const int32_t* child, const float* box, const int32_t* count, const uint32_t* order, int32_t root,
+                           int leaf_size, int max_depth, PtBvh* out)
+{
+    out->nodes.clear();
+    out->tris.clear();
+    out->root = -1;
+    out->depth = 0;
+    out->max_leaf = 0;
+    out->pad = 0.0f;
+    if (n_tris <= 0) return true;
+    leaf_size = std::max(1, std::min(7, leaf_size));
+    max_depth = std::max(2, std::min((int)PT_MAX_STACK, max_depth));
+    float ext = 0.0f;
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], positions[i * 3 + a]); mx[a] = std::max(mx[a], positions[i * 3 + a]); }
+        for (int a = 0; a < 3; ++a) { ext = std::max(ext, mx[a] - mn[a]); ext = std::max(ext, std::max(std::fabs(mn[a]), std::fabs(mx[a]))); }
+    }
+    const float pad = ext * 1e-5f; // as pt_bvh_build
+    out->pad = pad;
+    out->tris.reserve((size_t)n_tris);
+    out->nodes.reserve((size_t)n_tris / 2 + 16);
+    std::vector<int32_t> walk;
+    bool too_deep = false;
+    // returns the child reference of hierarchy node p; depth = internal nodes on the path including one created here
+    auto emit = [&](auto&& self, int32_t p, int depth) -> int32_t {
+        const int cnt = count[p];
+        if (cnt <= leaf_size) { // leaf: the triangles of the subtree, depth first
+            const uint32_t first = (uint32_t)out->tris.size();
+            walk.assign(1, p);
+            while (!walk.empty()) {
+                const int32_t q = walk.back();
+                walk.pop_back();
+                if (q < n_tris) {
+                    const uint32_t id = order[q];
+                    PtTri t;
+                    std::memcpy(t.p0, positions + (size_t)id * 9, 36);
+                    t.id = (int32_t)id;
+                    t.material = -1;
+                    t.pad = 0;
+                    out->tris.push_back(t);
+                } else {
+                    walk.push_back(child[2 * (size_t)q + 1]);
+                    walk.push_back(child[2 * (size_t)q]);
+                }
+            }
+            out->max_leaf = std::max(out->max_leaf, cnt);
+            return (int32_t)~((first << 3) | (uint32_t)cnt);
+        }
+        if (depth > max_depth) { too_deep = true; return -1; }
+        const int32_t idx = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        out->depth = std::max(out->depth, depth);
+        const int32_t l = child[2 * (size_t)p], r = child[2 * (size_t)p + 1];
+        const int32_t lc = self(self, l, depth + 1);
+        const int32_t rc = too_deep ? -1 : self(self, r, depth + 1);
+        PtNode& nd = out->nodes[(size_t)idx];
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a][0] = box[6 * (size_t)l + a] - pad; nd.hi[a][0] = box[6 * (size_t)l + 3 + a] + pad;
+            nd.lo[a][1] = box[6 * (size_t)r + a] - pad; nd.hi[a][1] = box[6 * (size_t)r + 3 + a] + pad;
+        }
+        nd.left = lc;
+        nd.right = rc;
+        nd.pad[0] = nd.pad[1] = 0;
+        return idx;
+    };
+    out->root = emit(emit, root, 1);
+    return !too_deep && (int32_t)out->tris.size() == n_tris;
+}
+
 // ---- host mirror of the kernel traversal (validation of the builder; same arithmetic as pt_kernel.hip) ----
 
 namespace {

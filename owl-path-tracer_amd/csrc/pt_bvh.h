@@ -38,3 +38,10 @@ bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float d
 // seven entries per level).  wide_leaves != 0: a subtree of <= 7 triangles that are contiguous in leaf order becomes one leaf
 // (lane k of a group tests triangle k).
 void pt_bvh_collapse8(const PtBvh& bvh, int wide_leaves, std::vector<PtNode8>* out, int32_t* root8, int* depth8);
+
+// A binary hierarchy over n triangles built elsewhere (the device PLOC builder, pt_lbvh.hip) turned into the layout of pt_types.h:
+// node i < n is the triangle order[i]; node i >= n has child[2i], child[2i + 1]; box[6i..] = {lo xyz, hi xyz}; count[i] = triangles
+// below.  Subtrees of at most leaf_size triangles become leaves, triangles go into depth-first order, boxes get the padding of
+// pt_bvh_build.  Returns false (out untouched in a usable way) if the tree is deeper than max_depth: the caller then builds on the host.
+bool pt_bvh_from_hierarchy(const float* positions, int32_t n_tris, const int32_t* child, const float* box, const int32_t* count, const uint32_t* order, int32_t root,
+                           int leaf_size, int max_depth, PtBvh* out);

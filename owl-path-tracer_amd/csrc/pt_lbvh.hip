@@ -352,3 +352,165 @@ extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_s
     *h_pad = pad;
     return hipGetLastError();
 }
+
+
+// =====================================================================================================================
+// PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) - option "bvh_builder" = 2 (round 3)
+// =====================================================================================================================
+// The Karras tree above splits at Morton-code bits; it is fast to build and 1.4x slower to walk than the host SAH tree
+// (profiles/r02_summary.md).  PLOC builds the tree bottom-up instead: the clusters (at first the triangles) stay in Morton
+// order; every cluster looks for the neighbour within `radius` positions whose union with it has the smallest surface area;
+// mutual nearest neighbours merge into a new node; the clusters are compacted; repeat until one is left.  Each round is three
+// small kernels and a scan; ~log n rounds.  The merge criterion is the surface-area heuristic itself, applied locally.
+// The device part delivers the hierarchy (children, boxes, triangle counts per node); the host turns it into the layout of
+// pt_types.h (pt_bvh_from_hierarchy: leaf collapse, triangles in depth-first order) - a linear pass.
+namespace {
+
+__device__ __forceinline__ float union_area(const Box6& a, const Box6& b)
+{
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_init(const float* __restrict__ pos, const unsigned long long* __restrict__ keys, int n, Box6* __restrict__ box,
+                                                  int2* __restrict__ child, int* __restrict__ count, int* __restrict__ cid)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    box[i] = tri_box(pos, (uint32_t)keys[i]);
+    child[i] = make_int2(-1, -1);
+    count[i] = 1;
+    cid[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_nn(const int* __restrict__ cid, int m, int radius, const Box6* __restrict__ box, int* __restrict__ nn)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const Box6 bi = box[cid[i]];
+    float best = INFINITY;
+    int bj = -1;
+    const int lo = max(0, i - radius), hi = min(m - 1, i + radius);
+    for (int j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        const float a = union_area(bi, box[cid[j]]);
+        if (a < best) { best = a; bj = j; } // ties: the smaller position (deterministic topology)
+    }
+    nn[i] = bj;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_merge(const int* __restrict__ cid, int m, const int* __restrict__ nn, Box6* __restrict__ box, int2* __restrict__ child,
+                                                   int* __restrict__ count, int n, int* __restrict__ counter, int* __restrict__ out, uint32_t* __restrict__ valid)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    if (j >= 0 && nn[j] == i) {
+        if (i < j) {
+            const int a = cid[i], b = cid[j];
+            const int p = n + atomicAdd(counter, 1);
+            const Box6 ba = box[a], bb = box[b];
+            Box6 u;
+            for (int k = 0; k < 3; ++k) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
+            box[p] = u;
+            child[p] = make_int2(a, b);
+            count[p] = count[a] + count[b];
+            out[i] = p;
+            valid[i] = 1u;
+        } else {
+            valid[i] = 0u;
+        }
+    } else {
+        out[i] = cid[i];
+        valid[i] = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ploc_compact(const int* __restrict__ out, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ offs, int m,
+                                                     int* __restrict__ cid_next)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m && valid[i]) cid_next[offs[i]] = out[i];
+}
+
+} // namespace
+
+extern "C" size_t pt_ploc_workspace_bytes(int n)
+{
+    size_t sort_tmp = 0, scan_tmp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0, 62);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, n);
+    const size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    const size_t N = (size_t)n;
+    // keys x2, cid x2, nn, out, valid, offs, box[2n], child[2n], count[2n], meta + counter, cub temp; 256-byte slack per array
+    return 2 * N * 8 + 6 * N * 4 + 2 * N * (sizeof(Box6) + 8 + 4) + sizeof(LbvhMeta) + 256 + tmp + 16 * 256;
+}
+
+// d_pos: n * 9 floats.  Host outputs (capacity 2n - 1 each unless stated): h_child (both -1 for node i < n: triangle h_order[i]), h_box (6 floats per
+// node), h_count (triangles below), h_order (n), *h_root, *h_rounds.
+extern "C" hipError_t pt_ploc_build_device(const float* d_pos, int n, int radius, void* d_workspace, size_t workspace_bytes, int* h_child, float* h_box, int* h_count,
+                                           uint32_t* h_order, int32_t* h_root, int32_t* h_rounds, hipStream_t stream)
+{
+    if (n < 2 || radius < 1 || workspace_bytes < pt_ploc_workspace_bytes(n)) return hipErrorInvalidValue;
+    char* w = (char*)d_workspace;
+    auto take = [&](size_t bytes) { char* p = w; w += (bytes + 255) & ~(size_t)255; return (void*)p; };
+    const size_t N = (size_t)n;
+    unsigned long long* keys = (unsigned long long*)take(N * 8);
+    unsigned long long* keys_sorted = (unsigned long long*)take(N * 8);
+    int* cid_a = (int*)take(N * 4);
+    int* cid_b = (int*)take(N * 4);
+    int* nn = (int*)take(N * 4);
+    int* out = (int*)take(N * 4);
+    uint32_t* valid = (uint32_t*)take(N * 4);
+    uint32_t* offs = (uint32_t*)take(N * 4);
+    Box6* box = (Box6*)take(2 * N * sizeof(Box6));
+    int2* child = (int2*)take(2 * N * 8);
+    int* count = (int*)take(2 * N * 4);
+    LbvhMeta* meta = (LbvhMeta*)take(sizeof(LbvhMeta));
+    int* counter = (int*)take(256);
+    void* cub_temp = (void*)w;
+    const size_t cub_temp_bytes = workspace_bytes - (size_t)(w - (char*)d_workspace);
+
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_init_meta, dim3(1), dim3(256), 0, stream, meta);
+    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, stream, d_pos, n, meta);
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, stream, d_pos, n, (const LbvhMeta*)meta, keys);
+    size_t tmp = cub_temp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(cub_temp, tmp, (const unsigned long long*)keys, keys_sorted, n, 0, 62, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(counter, 0, 4, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(256), 0, stream, d_pos, (const unsigned long long*)keys_sorted, n, box, child, count, cid_a);
+    int m = n, rounds = 0;
+    int* cid = cid_a;
+    int* cid_next = cid_b;
+    while (m > 1) {
+        const int mb = (m + 255) / 256;
+        hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(256), 0, stream, (const int*)cid, m, radius, (const Box6*)box, nn);
+        hipLaunchKernelGGL(k_ploc_merge, dim3(mb), dim3(256), 0, stream, (const int*)cid, m, (const int*)nn, box, child, count, n, counter, out, valid);
+        tmp = cub_temp_bytes;
+        e = hipcub::DeviceScan::ExclusiveSum(cub_temp, tmp, (const uint32_t*)valid, offs, m, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ploc_compact, dim3(mb), dim3(256), 0, stream, (const int*)out, (const uint32_t*)valid, (const uint32_t*)offs, m, cid_next);
+        uint32_t last_off = 0, last_valid = 0;
+        (void)hipMemcpyAsync(&last_off, offs + (m - 1), 4, hipMemcpyDeviceToHost, stream);
+        (void)hipMemcpyAsync(&last_valid, valid + (m - 1), 4, hipMemcpyDeviceToHost, stream);
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const int m_new = (int)(last_off + last_valid);
+        if (m_new >= m || m_new < 1 || ++rounds > 4096) return hipErrorUnknown; // the smallest union is always a mutual pair: every round merges
+        m = m_new;
+        int* t = cid; cid = cid_next; cid_next = t;
+    }
+    int root = 0;
+    (void)hipMemcpyAsync(&root, cid, 4, hipMemcpyDeviceToHost, stream);
+    hipLaunchKernelGGL(k_order, dim3(nb), dim3(256), 0, stream, (const unsigned long long*)keys_sorted, n, (uint32_t*)nn); // nn is free now
+    (void)hipMemcpyAsync(h_order, nn, N * 4, hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(h_child, child, (2 * N - 1) * 8, hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(h_box, box, (2 * N - 1) * sizeof(Box6), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(h_count, count, (2 * N - 1) * 4, hipMemcpyDeviceToHost, stream);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *h_root = root;
+    *h_rounds = rounds;
+    return hipGetLastError();
+}

@@ -16,6 +16,8 @@ hipError_t pt_kernel_geometry(int, int, int, int, int, int, int*, size_t*, int*,
 int pt_debug_block(void) { return 256; }
 size_t pt_lbvh_workspace_bytes(int) { return 16; }
 hipError_t pt_lbvh_build_device(const float*, int, int, void*, size_t, PtNode*, uint32_t*, int32_t*, int32_t*, int32_t*, int32_t*, float*, hipStream_t) { return hipErrorNotSupported; }
+size_t pt_ploc_workspace_bytes(int) { return 16; }
+hipError_t pt_ploc_build_device(const float*, int, int, void*, size_t, int*, float*, int*, uint32_t*, int32_t*, int32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_store_params(const PtKernelParams*, PtKernelParams*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_pack_rgba8(const float*, uint32_t*, long long, hipStream_t) { return hipErrorNotSupported; }
 }

@@ -696,8 +696,10 @@ def test_furnace_against_reference_rendered_images_gpu(gpu, orc, scene_io, proce
     np.testing.assert_array_equal(rgba, want8)
 
 
-def test_device_lbvh_builder(gpu, orc, cornell, scene_io, procedural):
-    """the BVH2 built on the device (option bvh_builder = 1, csrc/pt_lbvh.hip - Morton codes, radix sort, Karras' binary
+@pytest.mark.parametrize("builder", [1, 2])
+def test_device_lbvh_builder(gpu, orc, cornell, scene_io, procedural, builder):
+    """(builder 2, round 3: PLOC - bottom-up clustering by smallest union area among Morton neighbours, csrc/pt_lbvh.hip; the host lays
+    the hierarchy out, pt_bvh_from_hierarchy.)  SURVEY 8(f4): the BVH2 built on the device (option bvh_builder = 1, csrc/pt_lbvh.hip - Morton codes, radix sort, Karras' binary
     radix tree, bottom-up boxes, leaf collapse) replaces owlGroupBuildAccel (application.cpp:131-140).  Closest hit does not depend on
     the tree, so: 20 000 closest-hit queries bit-exact against the oracle's brute force, the product tree walked on the host agrees,
     and the image equals the oracle's bit for bit - for the cornell box (17 974 triangles) and for a 12-material scene; every leaf
@@ -705,11 +707,13 @@ def test_device_lbvh_builder(gpu, orc, cornell, scene_io, procedural):
     ctx = B.Context(0)
     try:
         for leaf in (1, 4, 7):
-            ctx.set_option("bvh_builder", 1)
+            ctx.set_option("bvh_builder", builder)
             ctx.set_option("leaf_size", leaf)
             _upload(ctx, cornell)
             st = ctx.stats()
             assert 0 < st["bvh_nodes"] < 17974 and 0 < st["bvh_depth"] <= 64, st
+            oi = ctx.oct_info()  # every triangle in exactly one leaf and inside its leaf's box (pt_debug_oct_info fails otherwise)
+            assert oi["triangles"] == 17974
             S = orc.Scene(cornell["flat"])
             rng = np.random.default_rng(11 + leaf)
             n = 20000 if leaf == 4 else 4000
@@ -737,7 +741,7 @@ def test_device_lbvh_builder(gpu, orc, cornell, scene_io, procedural):
         _upload(gpu, cornell)
         ref, _ = gpu.render(cam, W, H, 32, 16)
         assert_bitwise(got, ref, "device-built vs host-built BVH")
-        print("LBVH cornell: %d nodes depth %d build %.2f ms" % (ctx.stats()["bvh_nodes"], ctx.stats()["bvh_depth"], ctx.stats()["bvh_build_ms"]))
+        print("device builder %d, cornell: %d nodes depth %d build %.2f ms" % (builder, ctx.stats()["bvh_nodes"], ctx.stats()["bvh_depth"], ctx.stats()["bvh_build_ms"]))
     finally:
         ctx.close()
 

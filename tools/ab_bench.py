@@ -8,7 +8,7 @@ import ptamd
 ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
 
-PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align", "bvh_builder")  # builder / layout options: before upload_scene
+PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align", "bvh_builder", "ploc_radius", "wide_leaves")  # builder / layout options: before upload_scene
 NOT_OPTIONS = ("spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
 
 
