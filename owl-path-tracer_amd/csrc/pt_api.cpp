@@ -21,6 +21,7 @@ extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int 
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 extern "C" int pt_debug_block(void);
+extern "C" int pt_kernel_features(void);
 extern "C" hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream);
 extern "C" size_t pt_lbvh_workspace_bytes(int n);
 extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_size, void* d_workspace, size_t workspace_bytes, PtNode* d_nodes, uint32_t* d_order,
@@ -252,7 +253,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
-        DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
+        DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4q, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
                           &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
@@ -295,6 +296,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
+    else if (k == "quant") c->quant = value != 0; // wavefront kernel: 64-byte quad nodes on a 16-bit grid (default on)
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -444,6 +446,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_nodes = c->bvh.nodes.size();
     pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
+    if (!(pt_kernel_features() & 2) || c->nodes4.empty() || !pt_bvh_quantize4(c->nodes4, &c->nodes4q, c->quant_reach)) c->nodes4q.clear();
     pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8);
     if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
     { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
@@ -489,6 +492,7 @@ int upload_scene_to_device(pt_ctx* c)
     if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
     if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
     if ((rc = upload(c, c->d_nodes8, c->nodes8.data(), c->nodes8.size() * sizeof(PtNode8)))) return rc;
+    if ((rc = upload(c, c->d_nodes4q, c->nodes4q.data(), c->nodes4q.size() * sizeof(PtNode4Q)))) return rc;
     if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
     if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
     for (void* p : c->d_textures) (void)hipFree(p);
@@ -520,6 +524,8 @@ int clone_scene(pt_ctx* dst, const pt_ctx* src)
     dst->nodes4 = src->nodes4;
     dst->root4 = src->root4;
     dst->depth4 = src->depth4;
+    dst->nodes4q = src->nodes4q;
+    std::memcpy(dst->quant_reach, src->quant_reach, sizeof(dst->quant_reach));
     dst->nodes8 = src->nodes8;
     dst->root8 = src->root8;
     dst->depth8 = src->depth8;
@@ -608,7 +614,12 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.nodes4 = (const PtNode4*)c->d_nodes4.p;
         P.root = c->root4;
         P.stack_entries = 3 * c->depth4 + 1;
-        P.coop = c->coop;
+        P.coop = (pt_kernel_features() & 1) ? c->coop : 0;
+        // the same quad tree as 64-byte records with 8-bit planes - unless the camera is so far outside the scene that rounding its
+        // distance to a node's frame could eat the one-cell margin of the boxes (pt_bvh_quantize4); secondary rays start on surfaces
+        bool cam_ok = true;
+        for (int a = 0; a < 3; ++a) cam_ok = cam_ok && cam->origin[a] >= c->quant_reach[a][0] && cam->origin[a] <= c->quant_reach[a][1];
+        if ((pt_kernel_features() & 2) && c->quant && !c->nodes4q.empty() && !P.coop && cam_ok) P.nodes4q = (const PtNode4Q*)c->d_nodes4q.p;
     }
     if (c->kernel == 2 && c->groups && !c->nodes8.empty()) { // group walk of sparse waves (oct nodes)
         P.nodes8 = (const PtNode8*)c->d_nodes8.p;
@@ -624,12 +635,15 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
     // variant of the launch: the wavefront kernel's product instance (2) unless it needs scratch in this build - then its fallback
     // instance with the larger register budget (3): slower (12 instead of 16 waves per CU), the same arithmetic
-    int variant = c->kernel == 2 && c->fallback && !c->count ? 3 : c->kernel;
+    // (the one-level walk over PtNode[] - option quad = 0, or a tree too deep for the quad walk's stack bound - is compiled into the
+    // instrumented instance only: the product instance is kept small for the instruction cache)
+    const int use_count = (c->count || (c->kernel == 2 && !P.nodes4)) ? 1 : 0;
+    int variant = c->kernel == 2 && c->fallback && !use_count ? 3 : c->kernel;
     {
-        hipError_t ge = pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
-        if (ge == hipErrorInvalidConfiguration && variant == 2 && !c->count) {
+        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        if (ge == hipErrorInvalidConfiguration && variant == 2 && !use_count) {
             variant = 3;
-            ge = pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         }
         if (ge == hipErrorInvalidConfiguration)
             return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
@@ -640,7 +654,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(variant, c->count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -738,7 +752,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         if ((rc = ensure(c, c->d_rng, (size_t)W * H * 4))) return rc;
         if ((rc = ensure(c, c->d_accum, (size_t)W * H * 12))) return rc;
     }
-    if (c->count) {
+    if (use_count) {
         if ((rc = ensure(c, c->d_counters, sizeof(PtCounters)))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(PtCounters), stream));
     }
@@ -750,7 +764,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.accum = (float*)c->d_accum.p;
     P.out_rgb = (float*)d_out_rgb;
     P.out_rgba8 = (uint32_t*)d_out_rgba8;
-    P.counters = c->count ? (PtCounters*)c->d_counters.p : nullptr;
+    P.counters = use_count ? (PtCounters*)c->d_counters.p : nullptr;
     P.width = W;
     P.height = H;
     P.max_samples = max_samples;
@@ -808,7 +822,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         }
         const PtKernelParams* dP = (const PtKernelParams*)c->d_params.p + l; // one block per launch: launch l+1's copy never races launch l
         if (c->kernel == 2) HIP_TRY(c, pt_launch_store_params(&P, (PtKernelParams*)dP, stream)); // by value: P is reused for the next launch
-        HIP_TRY(c, pt_launch_render(&P, dP, variant, grid, lds, stream, c->count));
+        HIP_TRY(c, pt_launch_render(&P, dP, variant, grid, lds, stream, use_count));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->ev_pending = true;

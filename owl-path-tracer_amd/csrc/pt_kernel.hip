@@ -63,6 +63,14 @@ using namespace ptd;
 #ifndef PT_QUAD_REPS
 #define PT_QUAD_REPS 1 // quad-node steps per burst (a quad step is two binary levels and up to three pushes)
 #endif
+// Two validated experiments that did not pay stay in the source behind build switches (make EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1"):
+// in the product build they would only take room in the instruction cache, which the kernel fills (64 KB shared by two CUs).
+#ifndef PT_WITH_COOP
+#define PT_WITH_COOP 0  // cooperative node fetch through an LDS staging area (option "coop")
+#endif
+#ifndef PT_WITH_QUANT
+#define PT_WITH_QUANT 0 // 64-byte quad nodes with 8-bit planes (option "quant")
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -226,12 +234,32 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
 // the nearest hit child and pushes the other hit children (in slot order; any visiting order gives the same closest hit).
 // COOP: the record was staged in LDS by node4_fetch_coop (below); `rec` = this lane's 128 bytes there, chunk k at position k ^ rot.
 // Otherwise the lane reads its own record with 7 x global_load_dwordx4 = 7 vL1D accesses per lane and step.
-template <int STRIDE, int LDS_ENTRIES, bool COOP>
-__device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, const uint32_t* rec, int rot, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest,
+// QUANT: the 64-byte record with 8-bit planes in the node's own frame (PtNode4Q): four loads.  The ray goes into the frame - origin
+// (o - origin) / cell per axis, direction reciprocal x cell (t is unchanged: both are scaled per axis) - and a plane is its cell number
+// converted to float (v_cvt_f32_ubyteN).  The quantised box contains the float box with a margin of one cell, the frame origin of the
+// ray is off by less than an eighth of a cell, everything after that is the same monotone float arithmetic: the test stays
+// conservative (pt_types.h).  Empty slots are masked by their reference.
+template <int STRIDE, int LDS_ENTRIES, bool COOP, bool QUANT = false>
+__device__ __forceinline__ void node4_step(const void* __restrict__ nodes4, const uint32_t* rec, int rot, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest,
                                            int& cur, int& sp)
 {
     f32x4 lx, ly, lz, hx, hy, hz, cf;
-    if (COOP) {
+    if (QUANT) {
+        const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4Q);
+        const f32x4 a = ldg4(nodes4, nb), b = ldg4(nodes4, nb + 16), c = ldg4(nodes4, nb + 32);
+        cf = ldg4(nodes4, nb + 48);
+        // the cell sizes are powers of two: 1 / s is 0x7F000000 - bits(s), exactly
+        const float rsx = __uint_as_float(0x7F000000u - __float_as_uint(a.w)), rsy = __uint_as_float(0x7F000000u - __float_as_uint(b.x)),
+                    rsz = __uint_as_float(0x7F000000u - __float_as_uint(b.y));
+        o = V((o.x - a.x) * rsx, (o.y - a.y) * rsy, (o.z - a.z) * rsz);
+        inv = V(inv.x * a.w, inv.y * b.x, inv.z * b.y);
+#define PT_Q4(w) (float)((w) & 0xffu), (float)(((w) >> 8) & 0xffu), (float)(((w) >> 16) & 0xffu), (float)((w) >> 24)
+        const uint32_t w0 = __float_as_uint(b.z), w1 = __float_as_uint(b.w), w2 = __float_as_uint(c.x), w3 = __float_as_uint(c.y), w4 = __float_as_uint(c.z),
+                       w5 = __float_as_uint(c.w);
+        lx = (f32x4){PT_Q4(w0)}; ly = (f32x4){PT_Q4(w1)}; lz = (f32x4){PT_Q4(w2)};
+        hx = (f32x4){PT_Q4(w3)}; hy = (f32x4){PT_Q4(w4)}; hz = (f32x4){PT_Q4(w5)};
+#undef PT_Q4
+    } else if (COOP) {
         lx = *(const f32x4*)(rec + ((0 ^ rot) << 2)); ly = *(const f32x4*)(rec + ((1 ^ rot) << 2)); lz = *(const f32x4*)(rec + ((2 ^ rot) << 2));
         hx = *(const f32x4*)(rec + ((3 ^ rot) << 2)); hy = *(const f32x4*)(rec + ((4 ^ rot) << 2)); hz = *(const f32x4*)(rec + ((5 ^ rot) << 2));
         cf = *(const f32x4*)(rec + ((6 ^ rot) << 2));
@@ -261,6 +289,7 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, c
         hit[2 * p] = ta <= tf.x; hit[2 * p + 1] = tb <= tf.y;
     }
     const int r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
+    if (QUANT) { hit[0] = hit[0] && r0 != -1; hit[1] = hit[1] && r1 != -1; hit[2] = hit[2] && r2 != -1; hit[3] = hit[3] && r3 != -1; }
     const float far_key = kTMax * 2.0f; // beyond every valid entry distance
     const float k0 = hit[0] ? tn[0] : far_key, k1 = hit[1] ? tn[1] : far_key, k2 = hit[2] ? tn[2] : far_key, k3 = hit[3] ? tn[3] : far_key;
     const bool b01 = k1 < k0, b23 = k3 < k2;
@@ -833,8 +862,10 @@ __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
 
 // One shading pass over up to 64 entries of the hit queue (IS_MISS = false) or the miss queue (IS_MISS = true):
 // device.cu:136-214 for the hit/miss, then sample accumulation, next camera ray / next pixel (device.cu:229-254).
-template <bool COUNT, bool IS_MISS>
-__device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, int lane, Counters& cn)
+// (one instance serves both queues - is_miss is wave-uniform: the "next sample / next work item" half of the pass is the same code
+// either way, and two copies of it cost 4 KB of an instruction cache the kernel fills)
+template <bool COUNT>
+__device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, int lane, Counters& cn, const bool IS_MISS)
 {
     const int ns = w.ns;
     uint32_t* lray = w.lray;
@@ -844,8 +875,8 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 #define GF(f, s) gstate[(f) * ns + (s)]
 #define GFF(f, s) __uint_as_float(gstate[(f) * ns + (s)])
     uint8_t* q = IS_MISS ? w.missq : w.hitq;
-    int& q_head = IS_MISS ? w.miss_head : w.hit_head;
-    int& q_count = IS_MISS ? w.miss_count : w.hit_count;
+    int q_head = IS_MISS ? w.miss_head : w.hit_head;
+    int q_count = IS_MISS ? w.miss_count : w.hit_count;
     const int n = q_count < PT_WAVE ? q_count : PT_WAVE;
     const bool mine = lane < n;
     if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
@@ -949,6 +980,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     }
     q_head = w.wrap(q_head + n);
     q_count -= n;
+    if (IS_MISS) { w.miss_head = q_head; w.miss_count = q_count; } else { w.hit_head = q_head; w.hit_count = q_count; }
     const unsigned long long m_ray = __ballot(to_ray), m_hit = __ballot(to_hit), m_wait = __ballot(to_wait), m_dead = __ballot(died);
     if (to_ray) w.rayq[w.wrap(w.wrap(w.ray_head + w.ray_count) + rank_in(m_ray))] = (uint8_t)ps_slot;
     if (to_hit) w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_hit))] = (uint8_t)ps_slot;
@@ -1222,7 +1254,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     const int ns = P.ns;
     const int lds_stack = P.lds_levels; // pt_wave_lds_stack(), from the host
     // cooperative node fetch (P.coop): the first 8 KB of the wave's LDS are the staging area of node4_fetch_coop
-    const bool coop = P.coop != 0 && P.nodes4 != nullptr;
+    const bool coop = PT_WITH_COOP && P.coop != 0 && P.nodes4 != nullptr;
     uint32_t* stage = lds;
     uint32_t* lds0 = lds + (coop ? PT_STAGE_BYTES / 4 : 0);
     uint32_t* stack = lds0 + lane;                   // stack[level * 64], levels < PT_LDS_STACK
@@ -1240,6 +1272,8 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.missq = w.hitq + ns;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtNode4* __restrict__ nodes4 = P.nodes4;
+    const PtNode4Q* __restrict__ nodes4q = P.nodes4q;
+    const bool quant = PT_WITH_QUANT && nodes4q != nullptr; // the quad nodes as 64-byte records with 8-bit planes (host: option "quant")
     const PtTri* __restrict__ tris = P.tris;
 
 #define LF(f, s) lray[(f) * ns + (s)]
@@ -1287,16 +1321,12 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
             if (lane == 0) gp(P.error_flag)[0] = 1u;
             break;
         }
-        if (pick == PICK_HIT) {
-            shade_pass<COUNT, false>(P, w, lane, cn);
-            n_rounds = 0; // hits are always running paths: progress
+        if (pick != PICK_NONE) { // one call site: one copy of the pass in the instruction cache
+            const bool miss_pass = pick == PICK_MISS;
+            shade_pass<COUNT>(P, w, lane, cn, miss_pass);
+            if (!miss_pass || !w.miss_blocked) n_rounds = 0; // hits are always running paths; a miss pass may have done nothing but poll unpublished tickets
             w.retune(mb0, rl0, fb0);
-            if (COUNT) cn.cyc[3] += __builtin_amdgcn_s_memtime() - t0;
-        } else if (pick == PICK_MISS) {
-            shade_pass<COUNT, true>(P, w, lane, cn);
-            if (!w.miss_blocked) n_rounds = 0; // the pass did more than poll unpublished tickets
-            w.retune(mb0, rl0, fb0);
-            if (COUNT) cn.cyc[4] += __builtin_amdgcn_s_memtime() - t0;
+            if (COUNT) cn.cyc[miss_pass ? 4 : 3] += __builtin_amdgcn_s_memtime() - t0;
         } else if (starving) {
             // every live slot of this wave waits for a work item that another wave is still rendering
             __builtin_amdgcn_s_sleep(64);
@@ -1439,8 +1469,9 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
 #ifndef PT_COOP_ONLY
                             else if (cur >= 0) {
                                 if (COUNT) cn.nodes += nodes4 ? 2 : 1;
-                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
-                                else node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                                if (quant) node4_step<PT_WAVE, 0x7fffffff, false, true>(nodes4q, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                                else if (nodes4) node4_step<PT_WAVE, 0x7fffffff, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                                else if (COUNT) node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth); // the one-level walk exists in the instrumented instance only
                                 PT_STASH_LEAF(0x7fffffff);
                             }
 #endif
@@ -1450,8 +1481,9 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
 #endif
                     } else if (cur >= 0) { // some stack of the wave is about to leave LDS (rare): per-lane fetch, overflow-aware pushes
                         if (COUNT) cn.nodes += nodes4 ? 2 : 1;
-                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
-                        else node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.depth : nullptr);
+                        if (quant) node4_step<PT_WAVE, PT_LDS_STACK, false, true>(nodes4q, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                        else if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                        else if (COUNT) node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth);
                         if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;
                             if (sp > 0) {
@@ -1780,3 +1812,5 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
 }
 
 extern "C" int pt_debug_block(void) { return PT_BLOCK; }
+// which optional traversal variants this build contains: bit 0 cooperative node fetch, bit 1 quantised quad nodes
+extern "C" int pt_kernel_features(void) { return (PT_WITH_COOP ? 1 : 0) | (PT_WITH_QUANT ? 2 : 0); }
