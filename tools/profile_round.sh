@@ -13,7 +13,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
     i=$((i + 1))
     timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_$i --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i failed"; grep -m1 "error code" $out/pmc_$i.log; }
 done
-cd $root && python3 tools/pmc_summary.py "pt_render_wave_kernel<false>" $(for j in $(seq 1 $i); do echo $out/pmc_$j; done) > $out/pmc_summary.json
+cd $root && python3 tools/pmc_summary.py "pt_render_wave_kernel<false" $(for j in $(seq 1 $i); do echo $out/pmc_$j; done) > $out/pmc_summary.json
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 find $out/stats -name "*kernel_trace.csv" -exec cp {} $out/kernel_trace.csv \;
 rm -rf $out/stats

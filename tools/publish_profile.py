@@ -32,7 +32,7 @@ import bench as benchmod  # kernel_fingerprint(): bench.py quotes the PMC traffi
 
 rnd = int(name[1:3]) if name[:1] == "r" and name[1:3].isdigit() else 0
 traffic = {
-    "round": rnd, "kernel_fingerprint": benchmod.kernel_fingerprint(), "kernel": "pt_render_wave_kernel<false>, main launch (2nd of 2 per frame)",
+    "round": rnd, "kernel_fingerprint": benchmod.kernel_fingerprint(), "kernel": "pt_render_wave_kernel<false, 4>, main launch (2nd of 2 per frame)",
     "workload": "C4 dragon stand-in 1920x1080x1024spp depth 16, 1 GPU",
     "command": pmc["command"] + "; FETCH_SIZE and WRITE_SIZE in separate passes",
     "FETCH_SIZE_KB": pmc["counters_per_main_launch"]["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["counters_per_main_launch"]["WRITE_SIZE"],

@@ -4,7 +4,7 @@
 tag=$1
 out=gpurun_out/numbers_$tag.log
 : > $out
-for o in "" "shard_rank=5 shard_world=2" "shard_rank=5 shard_world=4" "shard_rank=5 shard_world=8" "shard_rank=5 shard_world=64" "shard_rank=5 shard_world=512"; do
+for o in "" "shard_rank=1 shard_world=2" "shard_rank=1 shard_world=4" "shard_rank=5 shard_world=8" "shard_rank=5 shard_world=64" "shard_rank=5 shard_world=512"; do
   python tools/ab_bench.py c4 3 chain=1 $o 2>&1 | tail -2 >> $out
 done
 python tools/ab_bench.py c2 3 chain=1 2>&1 | tail -2 >> $out
