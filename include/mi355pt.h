@@ -97,7 +97,7 @@ typedef struct pt_stats {
     double reduce_ms, d2h_ms;
     int32_t kernel_variant; /* 1 lane per pixel, 2 wavefront kernel, 3 its fallback instance with the larger register budget (chosen when
                              * the 128-VGPR instance of this build would need scratch, or by option "fallback") */
-    int32_t reserved;
+    int32_t express_pixels; /* pixels of the last cost-ordered launch that were rendered as express pixels (waves of their own) */
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */

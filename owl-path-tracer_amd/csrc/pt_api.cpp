@@ -293,6 +293,8 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     }
     else if (k == "wide_leaves") c->wide_leaves = value != 0; // oct nodes: subtrees of <= 7 triangles become one leaf (before pt_upload_scene)
     else if (k == "fallback") c->fallback = value != 0; // force the wavefront kernel's 168-VGPR fallback instance (tests)
+    else if (k == "express_permille") c->express_permille = (int)(value < 0 ? -1 : (value > 500 ? 500 : value)); // -1: automatic
+    else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
@@ -744,8 +746,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         if (n_chunks > 1) HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4 * (size_t)n_chunks, stream));
     }
     const int n_chunks = main_sc.n_chunks;
-    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 256))) return rc; // one ticket counter per launch, a cache line apart
-    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 256, stream));
+    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 512))) return rc; // per launch: the ticket counter and the express counter, 256 bytes apart
+    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 512, stream));
     HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
     if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
     if (n_launch > 1 || n_chunks > 1) {
@@ -786,13 +788,32 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.chunk_spp = main_sc.chunk;
     P.n_chunks = n_chunks;
     P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
+    // Express pixels (pt_kernel.hip, take_ticket): the most expensive entries of the cost-ordered queue get waves of their own when the
+    // frame is bound by its longest sample chains, i.e. when (nearly) every pixel is in flight from the start - few pixels per path slot
+    // (a shard of a multi-GPU frame, a small image).  A throughput-bound frame (many pixels per slot) has none: sparse waves would only
+    // take wave slots from it.  Options "express_permille" (-1 = automatic: 10 per mille up to 1.5 pixels per slot, 0 from 4),
+    // "ns_express" (8 pixels per express wave), at most an eighth of the waves.
+    uint32_t n_express = 0;
+    int express_waves = 0;
+    if (sorted && P.nodes8 && n_chunks <= 254 && (uint64_t)c->n_pixels * (uint64_t)n_chunks < 0xE0000000ull) {
+        const double ratio = (double)c->n_pixels / ((double)grid * (double)ns);
+        double permille = c->express_permille >= 0 ? (double)c->express_permille : (ratio <= 1.5 ? 10.0 : (ratio >= 4.0 ? 0.0 : 10.0 * (4.0 - ratio) / 2.5));
+        const int nse = std::max(1, std::min(c->ns_express, ns));
+        uint64_t want = (uint64_t)((double)c->n_pixels * permille / 1000.0);
+        want = std::min<uint64_t>(want, (uint64_t)(grid / 8) * (uint64_t)nse);
+        if (want > 0 && want < c->n_pixels) {
+            n_express = (uint32_t)want;
+            express_waves = (int)((want + (uint64_t)nse - 1) / (uint64_t)nse);
+            P.ns_express = nse;
+        }
+    }
     P.n_full = main_sc.n_full;
     for (int i = 0; i < PT_MAX_TAIL_CHUNKS; ++i) P.tail_len[i] = main_sc.tail_len[i];
 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     if (c->kernel == 2 && (rc = ensure(c, c->d_params, sizeof(PtKernelParams) * (size_t)n_launch))) return rc;
     for (int l = 0; l < n_launch; ++l) {
-        P.queue_head = (uint32_t*)c->d_heads.p + 64 * l;
+        P.queue_head = (uint32_t*)c->d_heads.p + 128 * l;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
         if (sorted) { // launch 0: cost pre-pass in queue order; launch 1: everything else, expensive pixels first
@@ -808,11 +829,15 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_chunks = 1;
                 P.n_full = 1;
                 P.n_tickets = c->n_pixels;
+                P.n_express = 0;
+                P.express_waves = 0;
             } else {
                 P.chunk_spp = main_sc.chunk;
                 P.n_chunks = n_chunks;
                 P.n_full = main_sc.n_full;
-                P.n_tickets = c->n_pixels * (uint32_t)n_chunks;
+                P.n_express = n_express;
+                P.express_waves = express_waves;
+                P.n_tickets = (c->n_pixels - n_express) * (uint32_t)n_chunks;
             }
             if (l == 1) {
                 HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, W, H, c->cost_radius, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p,
@@ -834,6 +859,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     c->last_h = H;
     c->stats.vgprs = vg;
     c->stats.kernel_variant = variant;
+    c->stats.express_pixels = n_express;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
     c->stats.block = block;

@@ -575,31 +575,51 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic
 __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define PT_NO_TICKET 0xfffffffeu // take_ticket: the queue is exhausted
+// EXPRESS PIXELS (round 3).  A pixel is one sequential chain of rays (device.cu:226-243) and a frame whose pixels all run at once -
+// one rank's shard of a multi-GPU frame, a small image - ends when its most expensive pixel does: chain length x per-ray turnaround,
+// which in a wave that is busy with 96 pixels is 35-55 us.  The n_express most expensive pixels of the cost-ordered queue (its
+// first entries) are therefore not mixed with the others: the first express_waves workgroups take ONLY them, ns_express at a time,
+// each for all of its samples in one go (chunk PT_WHOLE: no hand-offs), at raised wave priority (s_setprio) and - having at most
+// ns_express rays - with the group walk: a turnaround of 10-15 us.  The other waves share the remaining pixels as before and help
+// with express pixels once their own tickets are gone.  The image cannot change: a pixel's stream does not depend on who renders it.
+#define PT_EXPRESS 0xE0000000u  // ticket = PT_EXPRESS | index into the first n_express queue entries (the host keeps the bulk tickets below)
+#define PT_WHOLE 255u           // chunk index of "every sample of this launch" (n_chunks <= 254 when express pixels exist)
 // Next work item: tickets are handed out in order (hipcc aggregates the per-lane atomics of a pass into one per wave).
-__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P)
+__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, bool express_wave)
 {
-    const uint32_t t = take_agent(P.queue_head);
-    return t < P.n_tickets ? t : PT_NO_TICKET;
+    if (!express_wave) {
+        const uint32_t t = take_agent(P.queue_head);
+        if (t < P.n_tickets) return t;
+    }
+    if (P.n_express) {
+        const uint32_t e = take_agent(P.queue_head + 64); // the express counter: 256 bytes after the queue head
+        if (e < P.n_express) return PT_EXPRESS | e;
+    }
+    return PT_NO_TICKET;
 }
 
 // Try to start the work item of `ticket`.  Returns false if its ring cell is not published yet.
 __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ticket, uint32_t& c, int& px, int& py, uint32_t& rng, v3& color)
 {
     uint32_t pid;
-    if (ticket < P.n_pixels) {
-        pid = gp(P.pixel_ids)[ticket];
+    const uint32_t n_bulk = P.n_pixels - P.n_express; // queue entries [n_express, n_pixels) go through the chunk tickets
+    if ((ticket & 0xF0000000u) == PT_EXPRESS) {
+        pid = gp(P.pixel_ids)[ticket & 0x0FFFFFFFu];
+        c = PT_WHOLE;
+    } else if (ticket < n_bulk) {
+        pid = gp(P.pixel_ids)[P.n_express + ticket];
         c = 0;
     } else {
-        const uint32_t e = ld_agent(P.ring + ticket); // ring c = ticket / n_pixels, entry ticket % n_pixels; cell = pixel id + 1
+        const uint32_t e = ld_agent(P.ring + ticket); // ring c = ticket / n_bulk, entry ticket % n_bulk; cell = pixel id + 1
         if (e == 0u) return false;                    // chunk c - 1 of that pixel is still running somewhere
         pid = e - 1u;
-        c = ticket / P.n_pixels;
+        c = ticket / n_bulk;
     }
-    if (P.timeline && ticket % P.n_pixels == P.n_pixels - 1u) gp(P.lap_ticks)[(P.n_chunks + 1) + 1 + c] = wall_clock64(); // last start of chunk c
+    if (P.timeline && c != PT_WHOLE && ticket % n_bulk == n_bulk - 1u) gp(P.lap_ticks)[(P.n_chunks + 1) + 1 + c] = wall_clock64(); // last start of chunk c
     px = (int)(pid % (uint32_t)P.width);
     py = (int)(pid / (uint32_t)P.width);
     if (c == 0 && P.dbg_start) gp(P.dbg_start)[pid] = (uint32_t)wall_clock64();
-    if (c == 0 && P.sample_begin == 0) {
+    if ((c == 0 || c == PT_WHOLE) && P.sample_begin == 0) {
         rng = rng_init((uint32_t)px, (uint32_t)py); // device.cu:226
         color = vs(0.0f);
     } else {
@@ -612,13 +632,15 @@ __device__ __forceinline__ bool start_chunk(const PtKernelParams& P, uint32_t ti
 
 __device__ __forceinline__ int chunk_len(const PtKernelParams& P, uint32_t c)
 {
+    if (c == PT_WHOLE) return P.sample_count;
     return (int)c < P.n_full ? P.chunk_spp : P.tail_len[(int)c - P.n_full];
 }
 
 // The slot finished chunk c of its pixel: write the framebuffer (device.cu:246-253) or hand the pixel on.
 __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c, int px, int py, uint32_t rng, v3 color)
 {
-    const bool last_chunk = (int)c + 1 >= P.n_chunks;
+    const bool last_chunk = (int)c + 1 >= P.n_chunks; // (PT_WHOLE included)
+    const uint32_t n_bulk = P.n_pixels - P.n_express;
     const uint32_t pid = (uint32_t)px + (uint32_t)P.width * (uint32_t)py;
     if (c == 0 && P.dbg_start) { // diagnostics (tools/ab_bench.py latency=1): first-chunk duration by cost class of the pixel
         const uint32_t dt = (uint32_t)wall_clock64() - gp(P.dbg_start)[pid];
@@ -626,8 +648,8 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
         atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + cls, (unsigned long long)dt);
         atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + 32 + cls, 1ull);
     }
-    if (last_chunk && P.timeline) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
-        if (take_agent(P.ring_tail + P.n_chunks) == P.n_pixels - 1u) {
+    if (last_chunk && P.timeline && c != PT_WHOLE) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
+        if (take_agent(P.ring_tail + P.n_chunks) == n_bulk - 1u) {
             gp(P.lap_ticks)[P.n_chunks] = wall_clock64();
             gp(P.lap_ticks)[2 * (P.n_chunks + 1) + P.n_chunks] = pid;
         }
@@ -651,8 +673,8 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
         // leaves only after the state has left this CU
         const uint32_t pos = take_agent(P.ring_tail + (c + 1)); // completion order of chunk c = start order of chunk c + 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_agent(P.ring + (size_t)(c + 1) * P.n_pixels + pos, pid + 1u);
-        if (P.timeline && pos == P.n_pixels - 1u) {
+        st_agent(P.ring + (size_t)(c + 1) * n_bulk + pos, pid + 1u);
+        if (P.timeline && pos == n_bulk - 1u) {
             gp(P.lap_ticks)[c + 1] = wall_clock64();
             gp(P.lap_ticks)[2 * (P.n_chunks + 1) + c + 1] = pid;
         }
@@ -822,6 +844,7 @@ struct WaveCtx {
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     int ray_low, min_batch, full_batch; // shading-batch thresholds (PT_RAY_LOW, PT_MIN_BATCH, 64; pt_set_option "tune1".."tune3")
+    bool express;   // this wave renders express pixels only (take_ticket)
     int n_run;      // slots of this wave with a (pixel, chunk) running
     int adapt;      // 1: the thresholds follow n_run: a wave with few running pixels shades small batches instead of waiting for its slowest ray, and
                     // keeps stepping nodes while half of the lanes that started a burst still want to (1/8 shard of C4 391 -> 350 ms, 1/64 251 -> 214 ms)
@@ -925,7 +948,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                         gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = (uint8_t)cost;
                         cost = 0u;
                     }
-                    ticket = take_ticket(P); // in flight while finish_chunk stores the pixel's state
+                    ticket = take_ticket(P, w.express); // in flight while finish_chunk stores the pixel's state
                     finish_chunk(P, chunk, px, py, ps.rng, color);
                     have_pixel = false;
                     ended = true;
@@ -936,7 +959,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = take_ticket(P);
+                if (ticket == PT_FRESH) ticket = take_ticket(P, w.express);
                 if (ticket == PT_NO_TICKET) {
                     died = true;
                 } else if (start_chunk(P, ticket, chunk, px, py, ps.rng, color)) {
@@ -1286,6 +1309,10 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
         lstate[S_PIX * ns + i] = PT_FRESH;
         lstate[S_RNG * ns + i] = PT_FRESH;
     }
+    // express waves (take_ticket): few pixels, all of them long sample chains - the wave gets the SIMD when it asks for it
+    w.express = P.n_express != 0u && blockIdx.x < (uint32_t)P.express_waves;
+    const int ns_live = w.express ? (P.ns_express < ns ? P.ns_express : ns) : ns; // slots that ever get a pixel
+    if (w.express) __builtin_amdgcn_s_setprio(3);
     w.miss_blocked = false;
     w.min_batch = P.tune[1] > 0 ? P.tune[1] : PT_MIN_BATCH;
     w.ray_low = P.tune[2] > 0 ? P.tune[2] : PT_RAY_LOW;
@@ -1293,7 +1320,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     const int mb0 = w.min_batch, rl0 = w.ray_low, fb0 = w.full_batch;
     w.n_run = 0;
     w.adapt = P.tune[5] != 2; // option "adaptive" (default on; 2 = off)
-    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns; w.n_dead = 0;
+    w.ray_head = 0; w.ray_count = 0; w.hit_head = 0; w.hit_count = 0; w.miss_head = 0; w.miss_count = ns_live; w.n_dead = ns - ns_live;
     int n_parked = 0, n_rounds = 0;
     bool parked_groups = false; // what is parked belongs to a group phase (oct nodes, group stacks): it can only be resumed by one
     const int grp_max_rays = P.tune[6] > 0 ? P.tune[6] : PT_GROUP_MAX_RAYS, grp_max_run = P.tune[7] > 0 ? P.tune[7] : PT_GROUP_MAX_RUN; // options "tune6", "tune7"

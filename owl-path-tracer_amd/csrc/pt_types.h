@@ -146,7 +146,10 @@ struct PtKernelParams {
     int32_t lds_levels;        // wavefront kernel: stack levels kept in LDS (pt_wave_lds_stack)
     int32_t ns;                // wavefront kernel: path slots per wave (64..255)
     int32_t chunk_spp, n_chunks; // wavefront kernel: samples per (pixel, chunk) ticket and chunks per pixel
-    uint32_t n_tickets;        // n_pixels * n_chunks
+    uint32_t n_tickets;        // (n_pixels - n_express) * n_chunks
+    uint32_t n_express;        // the first n_express entries of the (cost-ordered) queue are express pixels (pt_kernel.hip, take_ticket); 0: none
+    int32_t express_waves;     // workgroups [0, express_waves) render express pixels only,
+    int32_t ns_express;        // ... this many at a time
     int32_t timeline;          // diagnostics: record the chunk timeline (pt_debug_read_laps); costs one more atomic per finished pixel
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)

@@ -598,6 +598,34 @@ def test_group_walk_bitwise(gpu, orc, cornell, scene_io, procedural):
         gpu.set_pixel_shard(0, 1, 16)
 
 
+def test_express_pixels_bitwise(gpu, orc, cornell):
+    """Round 3: the most expensive entries of the cost-ordered queue can be rendered as EXPRESS pixels - waves of their own, few pixels
+    each, every sample of a pixel in one go, group walk, raised wave priority (pt_kernel.hip take_ticket).  A pixel's stream does not
+    depend on who renders it: any share of express pixels and any number of them per wave gives the oracle's image; the other
+    waves must finish express pixels that are left over (more express pixels than express slots)."""
+    env = dict(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=B.make_env(**env))
+    W, H = 96, 72
+    cam = _cam(cornell, W, H)
+    want, _, cnt = orc.Scene(cornell["flat"]).render(_ocam(orc, cam), orc.make_env(**env), W, H, 40, 16, want_counters=True)
+    try:
+        for permille, nse in ((0, 8), (10, 8), (200, 4), (500, 1), (500, 64)):
+            gpu.set_option("express_permille", permille)
+            gpu.set_option("ns_express", nse)
+            gpu.set_option("count", 1)
+            got, _ = gpu.render(cam, W, H, 40, 16)
+            st = gpu.stats()
+            gpu.set_option("count", 0)
+            assert_bitwise(got, want, "express_permille=%d ns_express=%d" % (permille, nse))
+            assert (st["express_pixels"] > 0) == (permille > 0), (permille, st["express_pixels"])
+            for k in ("samples", "rays", "scatters"):
+                assert st[k] == cnt[k], (permille, nse, k)
+    finally:
+        gpu.set_option("express_permille", -1)
+        gpu.set_option("ns_express", 8)
+        gpu.set_option("count", 0)
+
+
 def test_vgpr_fallback_instance(gpu, orc, cube, scene_io):
     """The wavefront kernel's second instance (168-VGPR budget, 12 waves per CU) is what the library launches when the 128-VGPR
     instance of a build would need scratch; option "fallback" forces it.  Same source, same arithmetic: C1 bit for bit."""
