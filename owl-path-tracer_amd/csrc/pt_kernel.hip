@@ -1042,6 +1042,9 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 // image is bit-identical to the per-lane walk's - the parity suite runs with the group walk forced on as well (option groups = 2).
 // A group's stack is eight adjacent columns of the per-lane LDS stack area: entry e at stack[(e >> 3) * 64 + 8 * group + (e & 7)]
 // (capacity 8 * levels; the host enables the group walk only if 7 * depth8 + 1 entries fit, pt_api.cpp).
+#ifndef PT_GROUP_ORDERED
+#define PT_GROUP_ORDERED 1 // the hit children that are not entered go on the group's stack farthest first (0: in lane order)
+#endif
 #ifndef PT_GROUP_MAX_RAYS
 #define PT_GROUP_MAX_RAYS 16 // ray-queue level up to which a traversal phase uses the group walk (option groups = 1)
 #endif
@@ -1050,12 +1053,14 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 #endif
 
 namespace {
-__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
-__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
-__device__ __forceinline__ uint32_t dpp_xor3(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x1B, 0xf, 0xf, false); }  // quad_perm [3,2,1,0]
-__device__ __forceinline__ uint32_t dpp_mir8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); } // row_half_mirror
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ uint32_t dpp_xor3(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xf, 0xf, true); }  // quad_perm [3,2,1,0]
+__device__ __forceinline__ uint32_t dpp_mir8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); } // row_half_mirror
 __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// (bound_ctrl with a zero `old`: every lane of these patterns has a source lane, and in this form the compiler folds the DPP fetch into the
+// consuming instruction instead of a v_mov_b32_dpp per fetch)
 // one reduction stage of the leaf step: take the partner's candidate if it is better ((t, id) lexicographic)
 #define PT_HIT_STAGE(DPP)                                                                                           \
     {                                                                                                               \
@@ -1188,11 +1193,15 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
             // the other hit children go on the group's stack FARTHEST FIRST (the nearest of them is popped first): a pushing lane's
             // position is the number of pushing lanes with a larger key - seven cross-lane fetches: the three other lanes of its
             // quad, the mirror lane and the three other lanes of the mirror lane's quad
+            const uint32_t pbits = (uint32_t)(__ballot(push) >> gbase) & 0xffu; // this group's pushing lanes
+#if PT_GROUP_ORDERED
             const uint32_t pk = push ? key : 0u;
             const uint32_t pm = dpp_mir8(pk);
             const int prank = (int)(dpp_xor1(pk) > key) + (int)(dpp_xor2(pk) > key) + (int)(dpp_xor3(pk) > key) + (int)(pm > key) + (int)(dpp_xor1(pm) > key) +
                               (int)(dpp_xor2(pm) > key) + (int)(dpp_xor3(pm) > key);
-            const uint32_t pbits = (uint32_t)(__ballot(push) >> gbase) & 0xffu; // this group's pushing lanes
+#else
+            const int prank = __builtin_popcount(pbits & ((1u << sub) - 1u)); // lane order
+#endif
             if (push) {
                 const int e = sp + prank;
                 gstack[(e >> 3) * PT_WAVE + (e & 7)] = (uint32_t)ref;
