@@ -5,6 +5,16 @@
 #include <cmath>
 #include <cstring>
 
+#ifndef PT_SAH_BINS
+#define PT_SAH_BINS 64   // 16 -> 64 bins: 1.5 % fewer node visits on C4, 552 -> 541 ms (profiles/r03_notes.md)
+#endif
+#ifndef PT_SAH_LEAFCOUNT
+#define PT_SAH_LEAFCOUNT 0
+#endif
+#ifndef PT_SAH_SWEEP
+#define PT_SAH_SWEEP 0   // > 0: nodes of at most this many triangles are split by the exact sweep instead of bins (512: 0.2 % fewer node visits, 2x the build time)
+#endif
+
 namespace {
 
 struct Box {
@@ -28,6 +38,8 @@ struct Builder {
     PtBvh* out;
     int leaf_size, max_depth;
     float pad;
+    std::vector<int32_t> sweep_ids; // scratch of the exact sweep
+    std::vector<float> sweep_area;
 
     Box range_box(int lo, int hi) const
     {
@@ -67,8 +79,43 @@ struct Builder {
         if (!balanced && levels_needed(n, leaf_size) >= remaining) balanced = true;
 
         int mid = -1;
-        if (!balanced) {
-            constexpr int NB = 16;
+        // (PT_SAH_LEAFCOUNT = 1 counts leaves, ceil(n / leaf_size), instead of triangles - a leaf step requests the records of a whole
+        // leaf together - but fuller leaves cost more triangle tests than the saved node steps are worth: C4 +19 % tests, 541 -> 549 ms)
+        auto leaves_of = [&](int c) { return PT_SAH_LEAFCOUNT ? (float)((c + leaf_size - 1) / leaf_size) : (float)c; };
+        if (!balanced && n <= PT_SAH_SWEEP) {
+            // small node (most nodes are): the exact sweep - every split position along every axis, triangles sorted by centroid
+            float best = INFINITY;
+            int best_axis = -1, best_pos = -1;
+            std::vector<int32_t>& tmp = sweep_ids;
+            std::vector<float>& suffix = sweep_area;
+            tmp.resize((size_t)n);
+            suffix.resize((size_t)n + 1);
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(cb.mx[axis] - cb.mn[axis] > 0.0f)) continue;
+                std::copy(order.begin() + lo, order.begin() + hi, tmp.begin());
+                std::sort(tmp.begin(), tmp.end(), [&](int32_t a, int32_t b) {
+                    const float ca = cen[(size_t)a * 3 + axis], cbv = cen[(size_t)b * 3 + axis];
+                    return ca < cbv || (ca == cbv && a < b);
+                });
+                Box acc;
+                acc.reset();
+                for (int i = n - 1; i > 0; --i) { acc.grow(tb[tmp[(size_t)i]]); suffix[(size_t)i] = acc.half_area(); }
+                acc.reset();
+                for (int i = 0; i < n - 1; ++i) {
+                    acc.grow(tb[tmp[(size_t)i]]);
+                    const float cost = acc.half_area() * leaves_of(i + 1) + suffix[(size_t)i + 1] * leaves_of(n - i - 1);
+                    if (cost < best) { best = cost; best_axis = axis; best_pos = i + 1; }
+                }
+            }
+            if (best_axis >= 0) {
+                std::sort(order.begin() + lo, order.begin() + hi, [&](int32_t a, int32_t b) {
+                    const float ca = cen[(size_t)a * 3 + best_axis], cbv = cen[(size_t)b * 3 + best_axis];
+                    return ca < cbv || (ca == cbv && a < b);
+                });
+                mid = lo + best_pos;
+            }
+        } else if (!balanced) {
+            constexpr int NB = PT_SAH_BINS;
             float best = INFINITY;
             int best_axis = -1, best_bin = -1;
             for (int axis = 0; axis < 3; ++axis) {
@@ -97,16 +144,16 @@ struct Builder {
                     acc.grow(bb[b]);
                     c += cnt[b];
                     if (c == 0 || rc[b + 1] == 0) continue;
-                    float cost = acc.half_area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+                    float cost = acc.half_area() * leaves_of(c) + ra[b + 1] * leaves_of(rc[b + 1]);
                     if (cost < best) { best = cost; best_axis = axis; best_bin = b; }
                 }
             }
             if (best_axis >= 0) {
                 float lo_c = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
-                float scale = (float)16 / ext;
+                float scale = (float)PT_SAH_BINS / ext;
                 auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](int32_t id) {
                     int b = (int)((cen[(size_t)id * 3 + best_axis] - lo_c) * scale);
-                    b = b < 0 ? 0 : (b >= 16 ? 15 : b);
+                    b = b < 0 ? 0 : (b >= PT_SAH_BINS ? PT_SAH_BINS - 1 : b);
                     return b <= best_bin;
                 });
                 mid = (int)(it - order.begin());
