@@ -186,6 +186,86 @@ struct Builder {
     }
 };
 
+// Tree rotations (Kensler 2008) after the top-down build: at every internal node, bottom-up, one of its children may trade places
+// with a grandchild on the other side if that makes the other child's box smaller - the set of leaves below the node, hence its own
+// box, does not change.  Leaves stay what they are (ranges of the triangle array), only the topology above them moves.
+#ifndef PT_BVH_ROTATIONS
+#define PT_BVH_ROTATIONS 0 // passes over the tree (0: off)
+#endif
+static void rotate_tree(PtBvh* b, int max_depth, int passes)
+{
+    if (b->root < 0) return;
+    const std::vector<PtNode> saved = b->nodes;
+    const int saved_depth = b->depth;
+    auto area2 = [](const float lo[3], const float hi[3]) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<int32_t> post;
+    for (int pass = 0; pass < passes; ++pass) {
+        post.clear();
+        std::vector<int32_t> st{b->root};
+        while (!st.empty()) { // reverse pre-order = children before parents when walked backwards
+            const int32_t i = st.back();
+            st.pop_back();
+            post.push_back(i);
+            const PtNode& nd = b->nodes[(size_t)i];
+            if (nd.left >= 0) st.push_back(nd.left);
+            if (nd.right >= 0) st.push_back(nd.right);
+        }
+        long n_rot = 0;
+        for (size_t k = post.size(); k-- > 0;) {
+            PtNode& N = b->nodes[(size_t)post[k]];
+            int best_s = -1, best_g = -1;
+            float best_gain = 0.0f;
+            for (int s = 0; s < 2; ++s) {
+                const int32_t c = s ? N.right : N.left;
+                if (c < 0) continue;
+                const PtNode& C = b->nodes[(size_t)c];
+                float clo[3], chi[3], olo[3], ohi[3];
+                for (int a = 0; a < 3; ++a) { clo[a] = N.lo[a][s]; chi[a] = N.hi[a][s]; olo[a] = N.lo[a][1 - s]; ohi[a] = N.hi[a][1 - s]; }
+                const float a_c = area2(clo, chi);
+                for (int g = 0; g < 2; ++g) { // grandchild g of C goes up, the other child of N comes down next to C's child 1 - g
+                    float nlo[3], nhi[3];
+                    for (int a = 0; a < 3; ++a) { nlo[a] = std::min(olo[a], C.lo[a][1 - g]); nhi[a] = std::max(ohi[a], C.hi[a][1 - g]); }
+                    const float gain = a_c - area2(nlo, nhi);
+                    if (gain > best_gain) { best_gain = gain; best_s = s; best_g = g; }
+                }
+            }
+            if (best_s < 0) continue;
+            const int s = best_s, g = best_g;
+            const int32_t c = s ? N.right : N.left;
+            PtNode& C = b->nodes[(size_t)c];
+            int32_t& n_other = s ? N.left : N.right;
+            int32_t& c_up = g ? C.right : C.left;
+            // boxes: the one that goes up, the one that comes down
+            float ulo[3], uhi[3], dlo[3], dhi[3];
+            for (int a = 0; a < 3; ++a) { ulo[a] = C.lo[a][g]; uhi[a] = C.hi[a][g]; dlo[a] = N.lo[a][1 - s]; dhi[a] = N.hi[a][1 - s]; }
+            std::swap(n_other, c_up);
+            for (int a = 0; a < 3; ++a) {
+                C.lo[a][g] = dlo[a]; C.hi[a][g] = dhi[a];
+                N.lo[a][1 - s] = ulo[a]; N.hi[a][1 - s] = uhi[a];
+                N.lo[a][s] = std::min(C.lo[a][0], C.lo[a][1]); N.hi[a][s] = std::max(C.hi[a][0], C.hi[a][1]);
+            }
+            ++n_rot;
+        }
+        if (n_rot == 0) break;
+    }
+    // depth of the rotated tree; keep the original if the stack bound would be exceeded
+    int depth = 0;
+    std::vector<std::pair<int32_t, int>> st{{b->root, 1}};
+    while (!st.empty()) {
+        const auto [i, d] = st.back();
+        st.pop_back();
+        depth = std::max(depth, d);
+        const PtNode& nd = b->nodes[(size_t)i];
+        if (nd.left >= 0) st.push_back({nd.left, d + 1});
+        if (nd.right >= 0) st.push_back({nd.right, d + 1});
+    }
+    if (depth > max_depth) { b->nodes = saved; b->depth = saved_depth; }
+    else b->depth = depth;
+}
+
 } // namespace
 
 // ---- memory layout passes (the tree itself is untouched: same boxes, same topology, same leaf contents) -----------------------
@@ -519,6 +599,9 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
     out->pad = b.pad;
     out->nodes.reserve((size_t)n_tris);
     out->root = b.build(0, n_tris, 1, false);
+#if PT_BVH_ROTATIONS > 0
+    rotate_tree(out, max_depth, PT_BVH_ROTATIONS);
+#endif
     out->tris.resize(n_tris);
     for (int i = 0; i < n_tris; ++i) {
         int id = b.order[i];
