@@ -118,6 +118,23 @@ __device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, 
     return tn <= tf * 1.0000004f;
 }
 
+// Reciprocal direction of a ray FOR THE SLAB TESTS of the wavefront kernel: v_rcp_f32 (1 ulp) instead of the correctly rounded division
+// (ten instructions each, three per ray, in the refill step every lane runs through).  A slab distance is then off by a relative
+// 2^-23 at most, i.e. a plane seems displaced by < 1.2e-7 x its distance from the ray origin - every box is padded by 1e-5 x the scene
+// extent (pt_bvh.cpp), eighty times that - so the test stays conservative with respect to every hit the triangle test can report,
+// and the triangle test itself (which decides t, u, v and the image) does not use it.  0 -> inf like the division.
+#ifndef PT_FAST_RAY_INV
+#define PT_FAST_RAY_INV 1
+#endif
+__device__ __forceinline__ v3 ray_inv(v3 d)
+{
+#if PT_FAST_RAY_INV
+    return V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+#else
+    return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
+}
+
 // Moeller-Trumbore, two-sided, kTMin < t; ties in t go to the lower global id (order independent result).
 // tri_eval works on a record that is already in registers, so that a leaf step can issue the loads of all its triangles
 // before the first test (one memory round trip per leaf instead of one per triangle).
@@ -1104,7 +1121,7 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
             h.id = (int)park[K_BID * PT_WAVE];
             o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
             d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
-            inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            inv = ray_inv(d);
         }
     }
     int n_iter = 0;
@@ -1140,7 +1157,7 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
                     pslot = (int)w.rayq[w.wrap(w.ray_head + rk)];
                     o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
                     d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
-                    inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    inv = ray_inv(d);
                     cur = P.root8; // an oct node, or the leaf code of a scene of <= leaf_size triangles
                     sp = 0;
                     h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.slot = -1; h.id = 0x7fffffff;
@@ -1394,7 +1411,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                     pend = (int)park[K_PEND * PT_WAVE];
                     o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
                     d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
-                    inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    inv = ray_inv(d);
                 }
             }
             bool first = true;
@@ -1447,7 +1464,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                             pslot = (int)w.rayq[w.wrap(w.ray_head + rk)];
                             o = V(LFF(L_AX, pslot), LFF(L_AY, pslot), LFF(L_AZ, pslot));
                             d = V(LFF(L_DIRX, pslot), LFF(L_DIRY, pslot), LFF(L_DIRZ, pslot));
-                            inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            inv = ray_inv(d);
                             // a scene of <= leaf_size triangles has a leaf as its root: it starts as the stashed leaf
                             cur = P.root >= 0 ? P.root : PT_DONE;
                             sp = 0;
