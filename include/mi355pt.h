@@ -98,6 +98,7 @@ typedef struct pt_stats {
     int32_t kernel_variant; /* 1 lane per pixel, 2 wavefront kernel, 3 its fallback instance with the larger register budget (chosen when
                              * the 128-VGPR instance of this build would need scratch, or by option "fallback") */
     int32_t express_pixels; /* pixels of the last cost-ordered launch that were rendered as express pixels (waves of their own) */
+    int32_t whole_pixels;   /* other pixels of that launch that kept their path slot for all samples (whole-pixel schedule: every pixel had a slot from the start); 0: ring schedule */
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
@@ -233,6 +234,17 @@ int64_t pt_debug_read_queue(pt_ctx* ctx, uint32_t* queue_ids, uint32_t* input_id
  * at kernel entry, ticks[1 + c] = when the last pixel finished chunk c; then [0] unused, [1 + c] = when the last work item of
  * chunk c started; then [0] unused, [1 + c] = queue entry that finished chunk c last.  Returns the number of values written. */
 int64_t pt_debug_read_laps(pt_ctx* ctx, uint64_t* ticks, int64_t cap);
+
+/* With option "latency" = 1: per pixel (index x + width * y), ticks of the 100 MHz clock from the entry of the last cost-ordered main
+ * launch to the moment the pixel's last sample was stored (0 for pixels outside this rank's shard); then, if cap allows, a second
+ * array of the same size: rays traced per pixel in that launch (option "count" = 1, else zeros).  Returns the number of values
+ * written, 0 if the last render was not such a launch. */
+int64_t pt_debug_read_finish(pt_ctx* ctx, uint32_t* ticks, int64_t cap);
+
+/* Tier table of the last launch with the whole-pixel schedule (pt_stats.whole_pixels != 0): words[0] = number of tiers, then 8 words
+ * per tier: first queue entry, entries, pixels per wave, first workgroup, workgroups, cost class, 2 unused.  Returns the number of
+ * words written (at most 257), 0 if the last render used the ring schedule. */
+int64_t pt_debug_read_tiers(pt_ctx* ctx, uint32_t* words, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelPa
 extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
                                       size_t lds_bytes, hipStream_t stream);
 extern "C" size_t pt_sort_scratch_bytes(uint32_t n);
+extern "C" hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream);
 extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0,
                                             uint32_t* scratch, uint8_t* bucket, hipStream_t stream);
 extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
@@ -254,7 +255,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
         DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4q, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket, &c->d_tiers};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -294,6 +295,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "wide_leaves") c->wide_leaves = value != 0; // oct nodes: subtrees of <= 7 triangles become one leaf (before pt_upload_scene)
     else if (k == "fallback") c->fallback = value != 0; // force the wavefront kernel's 168-VGPR fallback instance (tests)
     else if (k == "express_permille") c->express_permille = (int)(value < 0 ? -1 : (value > 500 ? 500 : value)); // -1: automatic
+    else if (k == "whole") c->whole = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // whole-pixel schedule by cost class when every pixel can have a path slot: -1 the plan decides (default), 0 never, 1 always
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
@@ -664,6 +666,31 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     long want = ((long)c->n_pixels + ns - 1) / ns; // never more path slots than pixels: a pixel's chunks are sequential
     if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
     int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
+    const bool sorted = c->kernel == 2 && c->schedule == 1 && c->spp_per_launch == 0 && max_samples >= 4 * c->prepass_spp && max_samples <= 65535;
+    // Whole-pixel schedule (pt_kernel.hip, TIERS): when every pixel can have a path slot from the start, the main launch hands out
+    // pixels instead of (pixel, chunk) tickets, and every wave serves one cost class with as few pixels as that class needs - the plan
+    // is made on the device from the histogram of the counting sort (pt_plan_tiers_kernel).  Option "whole": -1 automatic, 0 never.
+    bool tiers = false;
+    int ring_grid = 0;
+    if (sorted && P.nodes8 && c->whole != 0 && c->slots_per_wave == 0 && occ > 0) {
+        const long capacity = (long)c->num_cus * bpc;
+        for (int nsd = 96; nsd <= 104 && !tiers; nsd += 8) { // 16 waves per CU up to 104 slots
+            if ((long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
+            want_ns = nsd;
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            if (occ >= bpc && ns == nsd) {
+                tiers = true;
+                ring_grid = (int)std::max(1L, std::min(((long)c->n_pixels + ns - 1) / ns, capacity)); // what the ring schedule would launch
+                grid = (int)capacity;
+            }
+        }
+        if (!tiers) {
+            want_ns = 96;
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+        }
+    }
+    uint32_t n_express = 0;
+    int express_waves = 0;
     if (state_words) {
         if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
         P.slot_state = (uint32_t*)c->d_slots.p;
@@ -699,7 +726,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // All schedules give the same image bit for bit (a pixel's stream does not depend on who renders it, or when).
     int S, n_launch;
     Schedule main_sc;
-    const bool sorted = c->kernel == 2 && c->schedule == 1 && c->spp_per_launch == 0 && max_samples >= 4 * c->prepass_spp && max_samples <= 65535;
     if (c->kernel == 1) {
         S = c->spp_per_launch > 0 ? std::min(c->spp_per_launch, max_samples) : max_samples;
         S = std::min(S, 65535);
@@ -746,8 +772,9 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         if (n_chunks > 1) HIP_TRY(c, hipMemsetAsync(c->d_ring.p, 0, (size_t)c->n_pixels * 4 * (size_t)n_chunks, stream));
     }
     const int n_chunks = main_sc.n_chunks;
-    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * 512))) return rc; // per launch: the ticket counter and the express counter, 256 bytes apart
-    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * 512, stream));
+    if ((rc = ensure(c, c->d_heads, (size_t)n_launch * PT_HEADS_WORDS * 4))) return rc; // per launch: the ticket counter, the express counter 256 bytes on, the tier counters
+    HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, (size_t)n_launch * PT_HEADS_WORDS * 4, stream));
+    if (tiers && (rc = ensure(c, c->d_tiers, (1 + PT_MAX_TIERS * PT_TIER_WORDS) * 4))) return rc;
     HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
     if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
     if (n_launch > 1 || n_chunks > 1) {
@@ -781,7 +808,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     P.dbg_start = nullptr;
     P.dbg_cost = nullptr;
     if (c->latency && sorted) {
-        if ((rc = ensure(c, c->d_dbg_start, (size_t)W * H * 4))) return rc;
+        if ((rc = ensure(c, c->d_dbg_start, (size_t)W * H * 8))) return rc; // + rays per pixel (instrumented instance)
+        HIP_TRY(c, hipMemsetAsync(c->d_dbg_start.p, 0, (size_t)W * H * 8, stream));
         P.dbg_cost = (uint8_t*)c->d_cost.p;
     }
     P.census_mode = c->census_mode;
@@ -793,18 +821,24 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // (a shard of a multi-GPU frame, a small image).  A throughput-bound frame (many pixels per slot) has none: sparse waves would only
     // take wave slots from it.  Options "express_permille" (-1 = automatic: 10 per mille up to 1.5 pixels per slot, 0 from 4),
     // "ns_express" (8 pixels per express wave), at most an eighth of the waves.
-    uint32_t n_express = 0;
-    int express_waves = 0;
     if (sorted && P.nodes8 && n_chunks <= 254 && (uint64_t)c->n_pixels * (uint64_t)n_chunks < 0xE0000000ull) {
-        const double ratio = (double)c->n_pixels / ((double)grid * (double)ns);
+        int& rgrid = tiers ? ring_grid : grid; // the workgroups of the ring schedule (with a tier plan the launch has all resident ones)
+        const double ratio = (double)c->n_pixels / ((double)rgrid * (double)ns);
         double permille = c->express_permille >= 0 ? (double)c->express_permille : (ratio <= 1.5 ? 10.0 : (ratio >= 4.0 ? 0.0 : 10.0 * (4.0 - ratio) / 2.5));
         const int nse = std::max(1, std::min(c->ns_express, ns));
         uint64_t want = (uint64_t)((double)c->n_pixels * permille / 1000.0);
-        want = std::min<uint64_t>(want, (uint64_t)(grid / 8) * (uint64_t)nse);
+        const int capacity = c->num_cus * bpc;
+        want = std::min<uint64_t>(want, (uint64_t)std::max(rgrid / 8, std::min(capacity / 2, capacity - rgrid)) * (uint64_t)nse);
         if (want > 0 && want < c->n_pixels) {
             n_express = (uint32_t)want;
             express_waves = (int)((want + (uint64_t)nse - 1) / (uint64_t)nse);
             P.ns_express = nse;
+            // wave slots the bulk does not fill (a shard, a small image) hold the express waves on top of the bulk's
+            rgrid = std::min(capacity, (int)(((long)c->n_pixels - (long)n_express + ns - 1) / ns) + express_waves);
+            if (state_words) {
+                if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
+                P.slot_state = (uint32_t*)c->d_slots.p;
+            }
         }
     }
     P.n_full = main_sc.n_full;
@@ -813,7 +847,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     if (c->kernel == 2 && (rc = ensure(c, c->d_params, sizeof(PtKernelParams) * (size_t)n_launch))) return rc;
     for (int l = 0; l < n_launch; ++l) {
-        P.queue_head = (uint32_t*)c->d_heads.p + 128 * l;
+        P.queue_head = (uint32_t*)c->d_heads.p + PT_HEADS_WORDS * l;
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
         if (sorted) { // launch 0: cost pre-pass in queue order; launch 1: everything else, expensive pixels first
@@ -831,6 +865,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_tickets = c->n_pixels;
                 P.n_express = 0;
                 P.express_waves = 0;
+                P.tiers = nullptr;
             } else {
                 P.chunk_spp = main_sc.chunk;
                 P.n_chunks = n_chunks;
@@ -838,10 +873,15 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_express = n_express;
                 P.express_waves = express_waves;
                 P.n_tickets = (c->n_pixels - n_express) * (uint32_t)n_chunks;
+                if (tiers) { // the plan decides on the device: pixels by cost class (then none of the above is used), or the ring schedule as prepared
+                    P.tiers = (const uint32_t*)c->d_tiers.p;
+                    P.ring_grid = ring_grid;
+                }
             }
             if (l == 1) {
                 HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, W, H, c->cost_radius, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p,
                                                  c->n_pixels, (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, (uint8_t*)c->d_bucket.p, stream));
+                if (tiers) HIP_TRY(c, pt_launch_plan_tiers((const uint32_t*)c->d_sort_scratch.p, c->n_pixels, grid, ns, c->whole > 0, (uint32_t*)c->d_tiers.p, stream));
                 HIP_TRY(c, hipEventRecord(c->evm, stream));
             }
         }
@@ -860,6 +900,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     c->stats.vgprs = vg;
     c->stats.kernel_variant = variant;
     c->stats.express_pixels = n_express;
+    c->stats.whole_pixels = tiers ? (int32_t)c->n_pixels : 0;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
     c->stats.block = block;
@@ -1093,6 +1134,30 @@ int64_t pt_debug_read_laps(pt_ctx* c, uint64_t* ticks, int64_t cap)
     int64_t n = 0; // the timeline, then the 64 latency accumulators, without the padding between them
     for (int i = 0; i < nt && n < cap; ++i) ticks[n++] = blk[(size_t)i];
     for (int i = 0; i < 64 && n < cap; ++i) ticks[n++] = blk[(size_t)PT_LAP_DIAG_OFS(c->last_chunks) + i];
+    return n;
+}
+
+int64_t pt_debug_read_tiers(pt_ctx* c, uint32_t* words, int64_t cap)
+{
+    if (!c || !words) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_read_tiers needs the GPU");
+    if (!c->stats.whole_pixels || !c->d_tiers.p) return 0;
+    const int64_t n = std::min<int64_t>(cap, 1 + PT_MAX_TIERS * PT_TIER_WORDS);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(words, c->d_tiers.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int64_t pt_debug_read_finish(pt_ctx* c, uint32_t* ticks, int64_t cap)
+{
+    if (!c || !ticks) return PT_E_INVALID;
+    if (c->host_only) return fail(c, PT_E_NO_DEVICE, "host-only context: pt_debug_read_finish needs the GPU");
+    if (c->kernel != 2 || !c->latency || !c->last_sorted || !c->d_dbg_start.p) return 0;
+    const int64_t n = std::min<int64_t>(cap, 2 * (int64_t)c->last_w * c->last_h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(ticks, c->d_dbg_start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return n;
 }
 

@@ -592,6 +592,11 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic
 __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomic_fetch_add(gp(p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define PT_NO_TICKET 0xfffffffeu // take_ticket: the queue is exhausted
+struct WaveTier {      // where this wave's pixels come from (wave-uniform)
+    uint32_t* counter; // tier schedule: the ticket counter of the wave's tier, else null
+    uint32_t q0, count; // ... and the tier's queue entries [q0, q0 + count)
+    bool express;      // ring schedule: this wave renders express pixels only
+};
 // EXPRESS PIXELS (round 3).  A pixel is one sequential chain of rays (device.cu:226-243) and a frame whose pixels all run at once -
 // one rank's shard of a multi-GPU frame, a small image - ends when its most expensive pixel does: chain length x per-ray turnaround,
 // which in a wave that is busy with 96 pixels is 35-55 us.  The n_express most expensive pixels of the cost-ordered queue (its
@@ -602,9 +607,22 @@ __device__ __forceinline__ uint32_t take_agent(uint32_t* p) { return __hip_atomi
 #define PT_EXPRESS 0xE0000000u  // ticket = PT_EXPRESS | index into the first n_express queue entries (the host keeps the bulk tickets below)
 #define PT_WHOLE 255u           // chunk index of "every sample of this launch" (n_chunks <= 254 when express pixels exist)
 // Next work item: tickets are handed out in order (hipcc aggregates the per-lane atomics of a pass into one per wave).
-__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, bool express_wave)
+// TIERS (whole-pixel schedule).  When every pixel of the launch can have a path slot from the start (a shard, a small image) the ring
+// schedule degenerates: tickets are handed out lap by lap, so no pixel starts chunk c + 1 before a slot holds the ticket of every pixel
+// still in chunk c - 1, and the cheap pixels wait at every lap for the expensive ones (75 % of the rays of a 1/8 shard of C4 were
+// traced by waves with idle slots, 842 M ring polls).  Such a frame is not bound by throughput but by its sample chains - rays of a
+// pixel x turnaround of a ray in the wave that holds it - and the turnaround is a property of the wave: 25-28 us with 4-8 pixels (group
+// walk), 35 / 43 with 12 / 16, ~50 with 32-48, 60-66 with 96 (measured on that shard, profiles/r03_logs/r3_ab37.log).  So the launch
+// hands out pixels, not chunks - a slot keeps its pixel for all samples - and every wave serves ONE cost class of the cost-ordered
+// queue with as few pixels as that class needs to finish with the others: pt_plan_tiers_kernel (below) turns the histogram of the
+// counting sort into a tier table on the device, and a wave looks up its tier by workgroup index.
+__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, const WaveTier& tier)
 {
-    if (!express_wave) {
+    if (tier.counter != nullptr) {
+        const uint32_t e = take_agent(tier.counter);
+        return e < tier.count ? PT_EXPRESS | (tier.q0 + e) : PT_NO_TICKET;
+    }
+    if (!tier.express) {
         const uint32_t t = take_agent(P.queue_head);
         if (t < P.n_tickets) return t;
     }
@@ -665,6 +683,7 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
         atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + cls, (unsigned long long)dt);
         atomicAdd(P.lap_ticks + PT_LAP_DIAG_OFS(P.n_chunks) + 32 + cls, 1ull);
     }
+    if (last_chunk && P.dbg_start) gp(P.dbg_start)[pid] = (uint32_t)(wall_clock64() - gp(P.lap_ticks)[0]); // diagnostics: when the pixel was done (pt_debug_read_finish)
     if (last_chunk && P.timeline && c != PT_WHOLE) { // ring_tail[n_chunks] only counts; the timeline is a diagnostic (pt_debug_read_laps)
         if (take_agent(P.ring_tail + P.n_chunks) == n_bulk - 1u) {
             gp(P.lap_ticks)[P.n_chunks] = wall_clock64();
@@ -825,7 +844,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_render_kernel(const PtKernelParam
 #define PT_LDS_STACK 12
 #endif
 enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
-// S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = chunk index (cost pre-pass: rays traced so far)
+// S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = chunk index (cost pre-pass: clock at the start of the pixel)
 enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
 // S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
@@ -861,7 +880,7 @@ struct WaveCtx {
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     int ray_low, min_batch, full_batch; // shading-batch thresholds (PT_RAY_LOW, PT_MIN_BATCH, 64; pt_set_option "tune1".."tune3")
-    bool express;   // this wave renders express pixels only (take_ticket)
+    WaveTier tier;  // take_ticket
     int n_run;      // slots of this wave with a (pixel, chunk) running
     int adapt;      // 1: the thresholds follow n_run: a wave with few running pixels shades small batches instead of waiting for its slowest ray, and
                     // keeps stepping nodes while half of the lanes that started a burst still want to (1/8 shard of C4 391 -> 350 ms, 1/64 251 -> 214 ms)
@@ -880,6 +899,19 @@ struct WaveCtx {
 
 // Which shading pass the wave should run next (0: none -> traverse).  Used both at the top of the wave loop and as the exit test
 // of the traversal phase, so the two can never disagree (a disagreement is a livelock: leave traversal, shade nothing, re-enter).
+// COST OF A PIXEL = TIME.  The cost pre-pass renders a few samples of every pixel and records how long they took in the slot that
+// rendered them (100 MHz clock; the slot's wave is dense and serves its pixels' rays in turn, so the duration is the pixel's sample
+// chain: rays x turnaround of ITS rays).  Rounds 1-3 counted rays instead; but a ray that grazes the dragon walks five times as many
+// nodes as one that leaves the floor for the sky, and two pixels with the same 2.2 rays per sample differ by 2x in the time their
+// chains take (the late half of a cost class of the 1/8 shard of C4: same rays, 60 instead of 30 us per ray).  The cost image holds
+// the duration as a class, 16 per doubling: class = 16 log2(duration / 1 us), 1..255 (1 us .. 63 ms); 0 = not this rank's pixel.
+__device__ __forceinline__ uint8_t pt_cost_class(uint32_t ticks)
+{
+    const float us = (float)ticks * 0.01f;
+    const int k = us > 1.0f ? (int)(16.0f * __log2f(us)) : 0;
+    return (uint8_t)(k < 1 ? 1 : (k > 255 ? 255 : k));
+}
+
 enum { PICK_NONE = 0, PICK_HIT = 1, PICK_MISS = 2 };
 __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
 {
@@ -928,7 +960,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         const bool running = pid != PT_FRESH;
         uint32_t ticket = running ? PT_FRESH : GF(S_RNG, ps_slot);
         const uint32_t qkc = running ? GF(S_QKC, ps_slot) : 0u;
-        // S_QKC: chunk index, or in the cost pre-pass (one chunk per pixel) the rays traced so far
+        // S_QKC: chunk index, or in the cost pre-pass (one chunk per pixel) the clock at which the slot started the pixel
         uint32_t chunk = P.cost_out ? 0u : qkc, cost = P.cost_out ? qkc : 0u;
         uint32_t pack = running ? GF(S_PACK, ps_slot) : 0u;
         int s = (int)(pack & 0xffffu);
@@ -949,7 +981,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             ps.retries = (int)(pack >> 25);
             ps.dir = V(LFF(L_DIRX, ps_slot), LFF(L_DIRY, ps_slot), LFF(L_DIRZ, ps_slot));
             if (COUNT) ++cn.rays;
-            cost = cost < 255u ? cost + 1u : 255u;
+            if (P.dbg_start && !P.cost_out) atomicAdd(P.dbg_start + (size_t)P.width * (size_t)P.height + (uint32_t)px + (uint32_t)P.width * (uint32_t)py, 1u); // diagnostics: rays per pixel
             v3 radiance;
             const int tslot = IS_MISS ? -1 : (int)LF(L_AZ, ps_slot);
             int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
@@ -961,11 +993,11 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 ++s;
                 need_gen = true;
                 if (s == chunk_len(P, chunk)) {
-                    if (P.cost_out) { // cost image, indexed by pixel id
-                        gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = (uint8_t)cost;
+                    if (P.cost_out) { // cost image, indexed by pixel id: how long the pre-pass's samples of this pixel took (pt_cost_class)
+                        gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = pt_cost_class((uint32_t)wall_clock64() - cost);
                         cost = 0u;
                     }
-                    ticket = take_ticket(P, w.express); // in flight while finish_chunk stores the pixel's state
+                    ticket = take_ticket(P, w.tier); // in flight while finish_chunk stores the pixel's state
                     finish_chunk(P, chunk, px, py, ps.rng, color);
                     have_pixel = false;
                     ended = true;
@@ -976,13 +1008,14 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = take_ticket(P, w.express);
+                if (ticket == PT_FRESH) ticket = take_ticket(P, w.tier);
                 if (ticket == PT_NO_TICKET) {
                     died = true;
                 } else if (start_chunk(P, ticket, chunk, px, py, ps.rng, color)) {
                     have_pixel = true;
                     started = true;
                     s = 0;
+                    if (P.cost_out) cost = (uint32_t)wall_clock64();
                 } else {
                     to_wait = true; // predecessor chunk still running somewhere: keep the ticket, poll again later
                 }
@@ -1336,9 +1369,32 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
         lstate[S_RNG * ns + i] = PT_FRESH;
     }
     // express waves (take_ticket): few pixels, all of them long sample chains - the wave gets the SIMD when it asks for it
-    w.express = P.n_express != 0u && blockIdx.x < (uint32_t)P.express_waves;
-    const int ns_live = w.express ? (P.ns_express < ns ? P.ns_express : ns) : ns; // slots that ever get a pixel
-    if (w.express) __builtin_amdgcn_s_setprio(3);
+    w.tier.counter = nullptr;
+    w.tier.q0 = w.tier.count = 0u;
+    w.tier.express = P.n_express != 0u && blockIdx.x < (uint32_t)P.express_waves;
+    int ns_live = w.tier.express ? (P.ns_express < ns ? P.ns_express : ns) : ns; // slots that ever get a pixel
+    if (P.tiers != nullptr) { // tier schedule: which cost class does this workgroup serve, and how many of its pixels at a time?
+        const uint32_t PT_AS1* tt = gp(P.tiers);
+        const uint32_t n_tiers = tt[0];
+        if (n_tiers == 0u) { // the plan chose the ring schedule (pt_plan_tiers_kernel): the launch has more workgroups than that wants
+            if (blockIdx.x >= (uint32_t)P.ring_grid) ns_live = 0;
+        } else {
+        ns_live = 1; // a workgroup beyond the plan finds its (null) tier empty and ends
+        w.tier.counter = P.queue_head + PT_TIER_COUNTER(0);
+        for (uint32_t t = 0; t < n_tiers; ++t) {
+            const uint32_t PT_AS1* e = tt + 1 + PT_TIER_WORDS * t;
+            if (blockIdx.x - e[3] < e[4]) {
+                w.tier.q0 = e[0];
+                w.tier.count = e[1];
+                ns_live = (int)e[2] < ns ? (int)e[2] : ns;
+                w.tier.counter = P.queue_head + PT_TIER_COUNTER(t);
+                break;
+            }
+        }
+        w.tier.express = ns_live <= PT_GROUP_MAX_RAYS;
+        }
+    }
+    if (w.tier.express) __builtin_amdgcn_s_setprio(3);
     w.miss_blocked = false;
     w.min_batch = P.tune[1] > 0 ? P.tune[1] : PT_MIN_BATCH;
     w.ray_low = P.tune[2] > 0 ? P.tune[2] : PT_RAY_LOW;
@@ -1678,34 +1734,46 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
 // the expensive pixels first (stable counting sort over PT_SORT_BUCKETS cost classes, so neighbours stay neighbours).
 #define PT_SORT_BLOCK 256
 #define PT_SORT_ITEMS 16
-#define PT_SORT_BUCKETS 16
+#define PT_SORT_BUCKETS 32
 
-// Cost of a pixel for the ordering: the maximum over its (2R+1)^2 neighbourhood of the rays the pre-pass counted.  Eight samples
-// are a noisy estimate, but expensive regions are spatially coherent; a truly expensive pixel that looked cheap would start
-// late and finish long after everything else (pixels of other ranks and outside the image count as 0).
+// Cost of a pixel for the ordering and the tier plan: the class the pre-pass recorded for it (pt_cost_class), de-noised.  A few
+// samples are a noisy estimate, and a pixel that is taken for cheaper than it is spends the frame in a wave that is too dense for it
+// and ends long after everything else.  Expensive regions are spatially coherent, so the estimate is the mean class (= geometric mean
+// of the durations) over those pixels of the (2R+1)^2 neighbourhood that look like the same surface - within +-PT_COST_BAND classes
+// (+-54 %) of the pixel's own - and never less than the pixel's own.  (The neighbourhood MAXIMUM - rounds 1 and 2 - is safe but puts
+// three times as many pixels into the expensive classes as belong there; the tier plan then runs out of waves.)  Pixels of other ranks
+// and outside the image hold 0 and take no part.
+#define PT_COST_BAND 10
 __device__ __forceinline__ uint32_t pixel_cost(const uint8_t* __restrict__ img, uint32_t pid, int W, int H, int R)
 {
     const int x = (int)(pid % (uint32_t)W), y = (int)(pid / (uint32_t)W);
-    uint32_t m = 0;
+    const int own = (int)img[pid];
+    int sum = 0, cnt = 0;
     for (int dy = -R; dy <= R; ++dy) {
         const int yy = y + dy;
         if (yy < 0 || yy >= H) continue;
         for (int dx = -R; dx <= R; ++dx) {
             const int xx = x + dx;
             if (xx < 0 || xx >= W) continue;
-            const uint32_t v = img[(size_t)yy * W + xx];
-            m = v > m ? v : m;
+            const int v = (int)img[(size_t)yy * W + xx];
+            if (v != 0 && v >= own - PT_COST_BAND && v <= own + PT_COST_BAND) { sum += v; ++cnt; }
         }
     }
-    return m;
+    const int mean = cnt ? (sum + cnt - 1) / cnt : own;
+    return (uint32_t)(mean > own ? mean : own);
 }
 
-__device__ __forceinline__ int cost_bucket(uint32_t cost, uint32_t c0)
+// Cost classes of the queue: PT_SORT_BUCKETS buckets of four pre-pass classes each (19 % wide), from class PT_COST_TOP (20 ms for the
+// pre-pass's samples of one pixel) down; everything below 80 us shares the last bucket.  0 = most expensive.
+#define PT_COST_TOP 230
+#define PT_TIER_MIN_SPREAD 6 // buckets between the median pixel and the 98th percentile (2.8x in time) from which the tier plan is used
+__device__ __forceinline__ int cost_bucket(uint32_t cls)
 {
-    const uint32_t extra = cost > c0 ? cost - c0 : 0u; // every sample traces at least its camera ray
-    const uint32_t b = extra * 3u / c0;                // 3 classes per extra ray/sample; >= 6 rays/sample share the top class
-    return PT_SORT_BUCKETS - 1 - (int)(b < (uint32_t)(PT_SORT_BUCKETS - 1) ? b : (uint32_t)(PT_SORT_BUCKETS - 1)); // 0 = most expensive
+    const int b = (PT_COST_TOP - (int)cls) / 4;
+    return b < 0 ? 0 : (b > PT_SORT_BUCKETS - 1 ? PT_SORT_BUCKETS - 1 : b);
 }
+// relative sample-chain duration of a pixel in `bucket`: the middle of the bucket
+__device__ __forceinline__ float bucket_time(int bucket) { return exp2f(((float)(PT_COST_TOP - 4 * bucket) - 1.5f) * 0.0625f); }
 
 __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8_t* __restrict__ img, const uint32_t* __restrict__ in, int W, int H, int R, uint32_t n,
                                                                     uint32_t c0, uint32_t* __restrict__ block_hist, uint8_t* __restrict__ bucket)
@@ -1715,7 +1783,7 @@ __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8
     __syncthreads();
     const uint32_t first = (blockIdx.x * PT_SORT_BLOCK + threadIdx.x) * PT_SORT_ITEMS;
     for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) {
-        const int b = cost_bucket(pixel_cost(img, in[i], W, H, R), c0);
+        const int b = cost_bucket(pixel_cost(img, in[i], W, H, R));
         bucket[i] = (uint8_t)b; // per queue entry, for the scatter pass
         atomicAdd(&h[b], 1u);
     }
@@ -1757,6 +1825,85 @@ __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scatter_kernel(const ui
     }
     __syncthreads();
     for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) out[cnt[bucket[i]][t]++] = in[i];
+}
+
+// ---- tier plan of the whole-pixel schedule (take_ticket) --------------------------------------------------------------------
+// Turnaround of a ray in a wave that holds n pixels, relative to a wave with 96: measured on a 1/8 shard of C4 with waves that hold
+// nothing but expensive pixels (profiles/r03_logs/r3_ab37.log: 25 / 28 / 35 / 43 / 56 / 48 / 49 us at 4 / 8 / 12 / 16 / 24 / 32 / 48 pixels,
+// 60-66 at 96).  Between 16 and 32 pixels a wave is neither: too many rays for the group walk (three phases in a row), too few for
+// the per-lane walk - the plan never uses 17..31.
+__device__ __forceinline__ float tier_turnaround(int n)
+{
+    const float xs[9] = {4.f, 8.f, 12.f, 16.f, 32.f, 48.f, 64.f, 96.f, 128.f};
+#ifndef PT_TIER_CURVE
+#define PT_TIER_CURVE 0.33f, 0.38f, 0.46f, 0.52f, 0.68f, 0.78f, 0.86f, 1.0f, 1.1f
+#endif
+    const float ys[9] = {PT_TIER_CURVE};
+    if (n <= 4) return ys[0];
+    for (int i = 1; i < 9; ++i)
+        if ((float)n <= xs[i]) return ys[i - 1] + (ys[i] - ys[i - 1]) * ((float)n - xs[i - 1]) / (xs[i] - xs[i - 1]);
+    return ys[8];
+}
+// pixels per wave for a class whose chain is `rays` long if the frame is to end at `T` (relative units): the most that still make it
+__device__ __forceinline__ int tier_pixels(float rays, float T, int ns)
+{
+    int best = 4;
+    for (int n = 4; n <= ns; n += (n < 16 ? 2 : (n == 16 ? 16 : 8))) // 4 6 .. 16, 32 40 .. ns
+        if (rays * tier_turnaround(n) <= T) best = n;
+    if (rays * tier_turnaround(ns) <= T) best = ns;
+    return best;
+}
+// One thread.  block_off: the scanned histogram of the sort (bucket b starts at queue entry block_off[b * nb]).  The frame time is the
+// largest chain x turnaround over the classes; bisect the smallest T whose plan fits the `capacity` resident waves.
+// The plan pays when the frame has a tail: a cheap majority and an expensive minority whose chains decide when it ends (a shard of the
+// dragon: the 98th percentile pixel takes ~10x the median pixel's time).  When all pixels cost about the same (the Cornell box: 1.4x)
+// homogeneous waves gain nothing over the ring schedule, which balances the waves' load chunk by chunk (C2: 75 vs 85 ms): unless
+// `force`, the table is then left empty and the launch runs the ring schedule the host prepared alongside.
+__global__ void pt_plan_tiers_kernel(const uint32_t* __restrict__ block_off, uint32_t nb, uint32_t n, int capacity, int ns, int force, uint32_t* __restrict__ tiers)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t start[PT_SORT_BUCKETS + 1];
+    for (int b = 0; b < PT_SORT_BUCKETS; ++b) start[b] = block_off[(size_t)b * nb];
+    start[PT_SORT_BUCKETS] = n;
+    if (!force) {
+        int b98 = 0, b50 = 0;
+        while (b98 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b98 + 1] * 50ull < (unsigned long long)n) ++b98;
+        while (b50 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b50 + 1] * 2ull < (unsigned long long)n) ++b50;
+        if (b50 - b98 < PT_TIER_MIN_SPREAD) { tiers[0] = 0u; return; }
+    }
+    float lo = 0.0f, hi = bucket_time(0) * tier_turnaround(ns) * 1.01f; // at hi every class runs ns pixels per wave
+    for (int it = 0; it < 20; ++it) {
+        const float T = 0.5f * (lo + hi);
+        long waves = 0;
+        for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
+            const uint32_t cnt = start[b + 1] - start[b];
+            if (cnt == 0u) continue;
+            const int per = tier_pixels(bucket_time(b), T, ns);
+            waves += (long)((cnt + (uint32_t)per - 1u) / (uint32_t)per);
+        }
+        if (waves <= (long)capacity) hi = T; else lo = T;
+    }
+    uint32_t n_tiers = 0, wave = 0;
+    for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
+        const uint32_t cnt = start[b + 1] - start[b];
+        if (cnt == 0u) continue;
+        const int per = tier_pixels(bucket_time(b), hi, ns);
+        const uint32_t w = (cnt + (uint32_t)per - 1u) / (uint32_t)per;
+        uint32_t* e = tiers + 1 + PT_TIER_WORDS * n_tiers;
+        e[0] = start[b]; e[1] = cnt; e[2] = (uint32_t)per; e[3] = wave; e[4] = w; e[5] = (uint32_t)b; e[6] = 0u; e[7] = 0u;
+        wave += w;
+        ++n_tiers;
+    }
+    tiers[0] = n_tiers;
+}
+
+extern "C" hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream)
+{
+    const uint32_t per_block = PT_SORT_BLOCK * PT_SORT_ITEMS;
+    const uint32_t nb = (n + per_block - 1) / per_block;
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_plan_tiers_kernel, dim3(1), dim3(1), 0, stream, scratch, nb, n, capacity, ns, force, tiers);
+    return hipGetLastError();
 }
 
 extern "C" size_t pt_sort_scratch_bytes(uint32_t n)

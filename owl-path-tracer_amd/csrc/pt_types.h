@@ -87,6 +87,13 @@ static_assert(sizeof(PtShade) == 64, "PtShade must be 64 bytes");
 
 #define PT_MAT_STRIDE 20 // material_data (17 floats) + texture slot + 2 pad: 80 bytes, 16-byte aligned rows
 #define PT_MAX_STACK 64
+// Tier table of the whole-pixel schedule (uint32 words): [0] number of tiers, then PT_TIER_WORDS per tier:
+// first queue entry, entries, pixels per wave, first workgroup, workgroups, cost class (diagnostics), 2 unused.  The ticket counter of tier t is
+// queue_head + PT_TIER_COUNTER(t) (a cache line of its own).
+#define PT_MAX_TIERS 32
+#define PT_TIER_WORDS 8
+#define PT_TIER_COUNTER(t) (128 + 32 * (t))
+#define PT_HEADS_WORDS (128 + 32 * PT_MAX_TIERS) // per launch: ticket counter, +64 express counter, then the tier counters
 #define PT_GROUP_STACK 96 // entries of a group's stack in the group walk: eight columns of the 12-level LDS stack area
 
 struct PtTexDesc {
@@ -150,6 +157,8 @@ struct PtKernelParams {
     uint32_t n_express;        // the first n_express entries of the (cost-ordered) queue are express pixels (pt_kernel.hip, take_ticket); 0: none
     int32_t express_waves;     // workgroups [0, express_waves) render express pixels only,
     int32_t ns_express;        // ... this many at a time
+    const uint32_t* tiers;     // != null: whole-pixel schedule by cost class (pt_kernel.hip, TIERS): the table pt_plan_tiers_kernel wrote for this launch
+    int32_t ring_grid;         // ... and if that table is empty (the plan chose the ring schedule): workgroups beyond this one have nothing to do
     int32_t timeline;          // diagnostics: record the chunk timeline (pt_debug_read_laps); costs one more atomic per finished pixel
     int32_t census_mode;       // instrumented build: 1 = the scheduler census covers only a wave's wind-down (after its first failed ticket)
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)

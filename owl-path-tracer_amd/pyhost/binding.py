@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("block", C.c_int32), ("grid", C.c_int32), ("stack_entries", C.c_int32),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("scatters", C.c_uint64),
                 ("env_misses", C.c_uint64), ("nan_retries", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8), ("reduce_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_variant", C.c_int32), ("express_pixels", C.c_int32)]
+                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8), ("reduce_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_variant", C.c_int32), ("express_pixels", C.c_int32), ("whole_pixels", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -62,7 +62,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upload_scene", "pt_set_materials", "pt_set_environment",
            "pt_set_pixel_shard", "pt_shard_pixels", "pt_render", "pt_render_device", "pt_synchronize", "pt_set_option", "pt_get_stats",
-           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps",
+           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps", "pt_debug_read_finish", "pt_debug_read_tiers",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_framebuffer", "pt_host_alloc", "pt_host_free",
            "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_ctx", "pt_group_last_error", "pt_group_upload_scene",
            "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info", "pt_debug_oct_info", "pt_debug_clone_scene"]
@@ -106,6 +106,10 @@ def lib():
     L.pt_debug_read_queue.restype = C.c_int64
     L.pt_debug_read_laps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
     L.pt_debug_read_laps.restype = C.c_int64
+    L.pt_debug_read_finish.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
+    L.pt_debug_read_finish.restype = C.c_int64
+    L.pt_debug_read_tiers.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
+    L.pt_debug_read_tiers.restype = C.c_int64
     u8p = C.POINTER(C.c_uint8)
     L.pt_comm_get_unique_id.argtypes = [u8p]
     L.pt_comm_init_rank.argtypes = [C.c_void_p, u8p, C.c_int32, C.c_int32]
@@ -340,6 +344,26 @@ class Context:
         if n < 0:
             self._check(int(n), "pt_debug_read_queue")
         return q[:n], i[:n], c[:n]
+
+    def read_finish(self, n_pixels):
+        """Per pixel (x + W * y): (ms from the entry of the main launch to the pixel's last sample, rays traced - with count = 1); option latency = 1."""
+        t = np.zeros(2 * n_pixels, np.uint32)
+        n = lib().pt_debug_read_finish(self._h, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size)
+        if n < 0:
+            self._check(int(n), "pt_debug_read_finish")
+        if n < 2 * n_pixels:
+            return t[:0].astype(np.float64), t[:0]
+        return t[:n_pixels].astype(np.float64) / 1e5, t[n_pixels:]
+
+    def read_tiers(self):
+        """Tiers of the last whole-pixel launch: list of dicts (first queue entry, pixels, pixels per wave, first workgroup, workgroups, cost class)."""
+        t = np.zeros(257, np.uint32)
+        n = lib().pt_debug_read_tiers(self._h, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size)
+        if n < 0:
+            self._check(int(n), "pt_debug_read_tiers")
+        if n == 0:
+            return []
+        return [dict(zip(("q0", "pixels", "per_wave", "wave0", "waves", "cost_class"), (int(x) for x in t[1 + 8 * i:7 + 8 * i]))) for i in range(int(t[0]))]
 
     def read_laps(self):
         """ms since kernel entry at which the last pixel finished chunk 0, 1, ... of the last wavefront launch."""

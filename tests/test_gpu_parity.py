@@ -235,33 +235,86 @@ def test_cornell_image_bitwise_and_golden(gpu, orc, cornell):
     assert st["kernel_ms"] > 0 and st["launches"] == 2  # cost pre-pass + main launch over the cost-ordered pixel queue
 
 
+def _queue_classes(ids, cost, q, W, H, R=2):
+    """cost_bucket(pixel_cost()) of pt_kernel.hip for the queue entries q: the pre-pass class of a pixel (16 per doubling of the time its
+    pre-pass samples took), replaced by the mean over the neighbours within +-10 classes if that is larger, in buckets of 4 from 230 down."""
+    img = np.zeros((H, W), np.int32)
+    img.reshape(-1)[ids] = cost
+    pad = np.pad(img, R)
+    sh = np.stack([pad[dy:dy + H, dx:dx + W] for dy in range(2 * R + 1) for dx in range(2 * R + 1)])
+    ok = (sh != 0) & (np.abs(sh - img[None]) <= 10)
+    cnt = ok.sum(0)
+    mean = np.where(cnt > 0, (np.where(ok, sh, 0).sum(0) + cnt - 1) // np.maximum(cnt, 1), img)
+    est = np.maximum(img, mean).reshape(-1)
+    return np.clip((230 - est[q]) // 4, 0, 31)
+
+
 def test_cost_ordered_queue_properties(gpu, cornell):
-    """The cost pre-pass + counting sort (default schedule from 32 spp): the queue is a permutation of the shard's pixels, ordered
-    by the 5x5 neighbourhood maximum of the pre-pass cost in non-increasing class order, and the costs are >= one ray per sample."""
+    """The cost pre-pass + counting sort (default schedule from 32 spp): the queue is a permutation of the shard's pixels in
+    non-increasing order of their de-noised time class (most expensive first), stable within a class."""
     env = B.make_env(color=(1, 1, 1), intensity=0.0)
     _upload(gpu, cornell, env=env)
     W, H = 96, 80
     cam = _cam(cornell, W, H)
     gpu.set_pixel_shard(1, 2, 16)
-    gpu.render(cam, W, H, 40, 16)
+    gpu.set_option("whole", 0)
+    try:
+        gpu.render(cam, W, H, 40, 16)
+    finally:
+        gpu.set_option("whole", -1)
     assert gpu.stats()["launches"] == 2 and gpu.stats()["prepass_ms"] > 0
     q, ids, cost = gpu.read_queue(W * H)
     gpu.set_pixel_shard(0, 1, 16)
     own = B.shard_pixels(W, H, 16, 1, 2)
     np.testing.assert_array_equal(ids, own)
     np.testing.assert_array_equal(np.sort(q), np.sort(own))
-    assert cost.min() >= 8 and cost.max() > 16  # 8 pre-pass samples, at least the camera ray each; the box interior bounces
-    img = np.zeros((H, W), np.int32)
-    img.reshape(-1)[ids] = cost
-    pad = np.pad(img, 2)
-    nmax = np.max([pad[dy:dy + H, dx:dx + W] for dy in range(5) for dx in range(5)], axis=0).reshape(-1)
-    cls = np.minimum(15, np.maximum(0, nmax[q] - 8) * 3 // 8)  # cost_bucket() of pt_kernel.hip, before the descending flip
-    assert np.all(np.diff(cls) <= 0), "queue classes must be non-increasing (most expensive first)"
+    assert cost.min() >= 1 and cost.max() > cost.min()  # a class per pixel of the shard (0 = not this rank's), and not all the same
+    cls = _queue_classes(ids, cost, q, W, H)
+    assert np.all(np.diff(cls) >= 0), "queue buckets must be non-decreasing (bucket 0 = most expensive first)"
     # stable within a class: input order is kept
     pos = np.empty(W * H, np.int64)
     pos[ids] = np.arange(ids.size)
     for c in np.unique(cls):
         assert np.all(np.diff(pos[q[cls == c]]) > 0)
+
+
+def test_tier_schedule_bitwise(gpu, orc, cornell):
+    """Whole-pixel schedule by cost class (pt_kernel.hip, TIERS): a launch whose pixels all have a path slot may hand out pixels instead
+    of (pixel, chunk) tickets, every wave serving one cost class.  Forced on, forced off and left to the plan: the same image bit
+    for bit (== the oracle's), and the tier table partitions the queue among workgroups that exist."""
+    env = dict(color=(1, 1, 1), intensity=0.0)
+    _upload(gpu, cornell, env=B.make_env(**env))
+    W, H, spp = 64, 48, 40
+    cam = _cam(cornell, W, H)
+    want, _, cnt = orc.Scene(cornell["flat"]).render(_ocam(orc, cam), orc.make_env(**env), W, H, spp, 16, want_counters=True)
+    try:
+        for whole, count in ((1, 0), (1, 1), (0, 0), (-1, 0)):
+            gpu.set_option("whole", whole)
+            gpu.set_option("count", count)
+            got, _ = gpu.render(cam, W, H, spp, 16)
+            st = gpu.stats()
+            gpu.set_option("count", 0)
+            assert_bitwise(got, want, "whole=%d count=%d" % (whole, count))
+            if count:
+                for k in ("samples", "rays", "scatters"):
+                    assert st[k] == cnt[k], (whole, k)
+            tiers = gpu.read_tiers()
+            if whole == 1:
+                assert st["whole_pixels"] == W * H and tiers, (st["whole_pixels"], tiers)
+                q0 = 0
+                for t in tiers:  # consecutive queue ranges, workgroup ranges one after the other, pixels per wave within the menu
+                    assert t["q0"] == q0 and t["pixels"] > 0 and 4 <= t["per_wave"] <= 104
+                    assert t["waves"] * t["per_wave"] >= t["pixels"] > (t["waves"] - 1) * t["per_wave"]
+                    q0 += t["pixels"]
+                assert q0 == W * H
+                assert [t["wave0"] for t in tiers] == list(np.cumsum([0] + [t["waves"] for t in tiers[:-1]]))
+                assert tiers[-1]["wave0"] + tiers[-1]["waves"] <= st["grid"]
+                assert [t["cost_class"] for t in tiers] == sorted(t["cost_class"] for t in tiers)
+            if whole == 0:
+                assert st["whole_pixels"] == 0 and not tiers
+    finally:
+        gpu.set_option("whole", -1)
+        gpu.set_option("count", 0)
 
 
 def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
@@ -609,6 +662,7 @@ def test_express_pixels_bitwise(gpu, orc, cornell):
     cam = _cam(cornell, W, H)
     want, _, cnt = orc.Scene(cornell["flat"]).render(_ocam(orc, cam), orc.make_env(**env), W, H, 40, 16, want_counters=True)
     try:
+        gpu.set_option("whole", 0)  # the ring schedule (a tier plan would serve these pixels by cost class instead: test_tier_schedule_bitwise)
         for permille, nse in ((0, 8), (10, 8), (200, 4), (500, 1), (500, 64)):
             gpu.set_option("express_permille", permille)
             gpu.set_option("ns_express", nse)
@@ -624,6 +678,7 @@ def test_express_pixels_bitwise(gpu, orc, cornell):
         gpu.set_option("express_permille", -1)
         gpu.set_option("ns_express", 8)
         gpu.set_option("count", 0)
+        gpu.set_option("whole", -1)
 
 
 def test_vgpr_fallback_instance(gpu, orc, cube, scene_io):

@@ -9,7 +9,7 @@ ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
 
 PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align", "bvh_builder", "ploc_radius", "wide_leaves")  # builder / layout options: before upload_scene
-NOT_OPTIONS = ("spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
+NOT_OPTIONS = ("finish", "tiers", "spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
 
 
 def main():
@@ -61,6 +61,47 @@ def main():
         ctx.render(cam, W, H, spp, 16)
         ms.append(ctx.stats()["kernel_ms"])
     st = ctx.stats()
+    if opts.get("tiers"):
+        print(json.dumps({"tiers(pixels,per_wave,waves,class)": [(t["pixels"], t["per_wave"], t["waves"], t["cost_class"]) for t in ctx.read_tiers()]}))
+    if opts.get("finish"):
+        # when was each pixel done (needs latency=1)?  How many pixels are still running as the frame drains, and how fast are the last ones served?
+        q, ids, cost = ctx.read_queue(W * H)
+        fin, nrays = ctx.read_finish(W * H)
+        if fin.size and ids.size:
+            f = fin[ids.astype(np.int64)]
+            total = float(f.max())
+            rays = np.maximum(cost.astype(np.float64), 1.0) / 8.0 * (spp - 8)
+            if nrays.any():  # count=1: the real thing
+                est = rays
+                rays = np.maximum(nrays[ids.astype(np.int64)].astype(np.float64), 1.0)
+                print(json.dumps({"true_rays_over_estimate(p1,p10,p50,p90,p99)": [round(float(x), 2) for x in np.percentile(rays / est, [1, 10, 50, 90, 99])],
+                                  "pixels_with_rays_ge": {str(k): int((rays >= k).sum()) for k in (1500, 2000, 2500, 3000, 4000, 5000, 6000, 8000)}}))
+            us = f * 1e3 / rays
+            nexp = ctx.stats().get("express_pixels", 0)
+            pos = np.empty(W * H, np.int64); pos[:] = 1 << 40
+            pos[q.astype(np.int64)] = np.arange(q.size)
+            is_exp = pos[ids.astype(np.int64)] < nexp
+            order = np.argsort(-f)
+            out = {"pixels_with_cost_ge": {str(k): int((cost >= k).sum()) for k in (8, 12, 16, 20, 24, 32, 40, 48, 64)}, "last_pixel_ms": round(total, 2), "n_pixels": int(ids.size), "n_express": int(nexp),
+                   "running_at_pct_of_time": {str(pc): int((f > total * pc / 100.0).sum()) for pc in (10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 99)},
+                   "rays_left_at_pct_of_time": {str(pc): round(float((rays * np.clip((f - total * pc / 100.0) / np.maximum(f, 1e-9), 0, 1)).sum() / rays.sum()), 4) for pc in (10, 20, 30, 40, 50, 60, 70, 80, 90)},
+                   "last_finishers(cost,ms,us_per_ray,express)": [(int(cost[i]), round(float(f[i]), 1), round(float(us[i]), 1), bool(is_exp[i])) for i in order[:12]],
+                   "top_cost(cost,ms,us_per_ray,express)": [(int(cost[i]), round(float(f[i]), 1), round(float(us[i]), 1), bool(is_exp[i])) for i in np.argsort(-cost.astype(np.int64))[:12]],
+                   "us_per_ray_express(p10,p50,p90)": [round(float(x), 1) for x in np.percentile(us[is_exp], [10, 50, 90])] if is_exp.any() else None,
+                   "us_per_ray_bulk_by_cost_class(cost>>5: p50)": {str(k): round(float(np.median(us[(~is_exp) & ((cost >> 5) == k)])), 1) for k in range(8) if ((~is_exp) & ((cost >> 5) == k)).any()},
+                   "finish_ms_express(p10,p50,p90,max)": [round(float(x), 1) for x in np.percentile(f[is_exp], [10, 50, 90, 100])] if is_exp.any() else None}
+            print(json.dumps(out))
+            tiers = ctx.read_tiers()
+            if tiers:  # per tier: pixels per wave, true rays (median), finish time (median, max), us per ray (median)
+                fq = fin[q.astype(np.int64)]; rq = np.maximum(nrays[q.astype(np.int64)].astype(np.float64), 1.0) if nrays.any() else None
+                rows = []
+                for t in tiers:
+                    sl = slice(t["q0"], t["q0"] + t["pixels"])
+                    if t["pixels"] < 20 or rq is None: continue
+                    ff = fq[sl]; rr = rq[sl]; late = ff > 1.5 * np.median(ff)
+                    rows.append((t["cost_class"], t["pixels"], t["per_wave"], int(np.median(rr)), round(float(np.median(ff)), 1), round(float(np.percentile(ff, 90)), 1), round(float(np.percentile(ff, 99)), 1), round(float(ff.max()), 1),
+                                 round(float(np.median(ff * 1e3 / rr)), 1), int(late.sum()), int(np.median(rr[late])) if late.any() else 0, round(float(np.median(ff[late] * 1e3 / rr[late])), 1) if late.any() else 0))
+                print(json.dumps({"per_tier(class,pixels,per_wave,rays_p50,finish_p50,p90,p99,max,us_per_ray_p50,n_late(>1.5x p50),late_rays_p50,late_us_per_ray_p50)": rows}))
     if opts.get("count"):
         pass
     if "shard_rank" in opts or opts.get("census"):

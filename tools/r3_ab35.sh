@@ -1,0 +1,3 @@
+#!/bin/bash
+python tools/ab_bench.py c4 2 shard_rank=1 shard_world=8 latency=1 finish=1 2>&1 | tail -4 | cut -c1-2800
+python tools/ab_bench.py c2 2 latency=1 finish=1 2>&1 | tail -3 | cut -c1-2800
