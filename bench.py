@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 W, H, SPP, DEPTH = 1920, 1080, 1024, 16
-PREPASS_SPP = 8  # library default ("prepass_spp"): samples per pixel of the cost pre-pass launch
+PREPASS_SPP = 8  # samples per pixel of the cost pre-pass launch unless pt_stats says otherwise (16 when a tier plan is prepared: shards)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -245,7 +245,8 @@ def main():
         alg_frame = algorithmic_bytes(cst, own_pixels)  # this rank's frame, both launches
         # The dominant kernel launch is the main one (launch 2 of 2 per frame): samples PREPASS_SPP.. of every pixel.  Counted work
         # is per frame; per-sample work does not depend on the sample index, so the main launch carries (SPP - PREPASS_SPP) / SPP.
-        main_share = (SPP - PREPASS_SPP) / SPP if launches > 1 else 1.0
+        pre_spp = int(st.get("prepass_spp", 0)) or PREPASS_SPP
+        main_share = (SPP - pre_spp) / SPP if launches > 1 else 1.0
         alg_bytes = alg_frame * main_share
         main_ms = k_ms - p_ms
         achieved = alg_bytes / (main_ms * 1e-3) / 1e9
@@ -271,7 +272,7 @@ def main():
             "config": {"workload": "C4 dragon.json on the 871400-triangle stand-in (dragon.obj.scene is a missing blob), 1920x1080, 1024 spp, "
                                    "max_path_depth 16, environment intensity 0, areaLight emission 30",
                        "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer inside the library (pt_comm_init_rank)" % (D.TILE, D.TILE, world),
-                       "kernel": "wavefront-scheduled megakernel; per frame: cost pre-pass launch (%d spp) + queue sort + one persistent main launch" % PREPASS_SPP, "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
+                       "kernel": "wavefront-scheduled megakernel; per frame: cost pre-pass launch (%d spp) + queue sort + one persistent main launch" % (int(st.get("prepass_spp", 0)) or PREPASS_SPP), "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
                        "bvh_depth": int(st["bvh_depth"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(world),

@@ -99,6 +99,7 @@ typedef struct pt_stats {
                              * the 128-VGPR instance of this build would need scratch, or by option "fallback") */
     int32_t express_pixels; /* pixels of the last cost-ordered launch that were rendered as express pixels (waves of their own) */
     int32_t whole_pixels;   /* other pixels of that launch that kept their path slot for all samples (whole-pixel schedule: every pixel had a slot from the start); 0: ring schedule */
+    int32_t prepass_spp;    /* samples per pixel of the cost pre-pass launch of the last render (0: the render did not sort) */
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */

@@ -283,7 +283,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "latency") c->latency = (int)value;
     else if (k == "census_mode") c->census_mode = (int)value;
     else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
-    else if (k == "prepass_spp") c->prepass_spp = (int)(value < 1 ? 1 : (value > 15 ? 15 : value));
+    else if (k == "prepass_spp") c->prepass_spp = (int)(value < 0 ? 0 : (value > 64 ? 64 : value)); // 0: automatic (8; 16 when a tier plan is prepared)
     else if (k == "chunk_tail_min") c->chunk_tail_min = (int)(value < 0 ? 0 : (value > 65535 ? 65535 : value));
     else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
     else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
@@ -666,7 +666,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     long want = ((long)c->n_pixels + ns - 1) / ns; // never more path slots than pixels: a pixel's chunks are sequential
     if (c->kernel == 1) want = ((long)c->n_pixels + block - 1) / block;
     int grid = (int)std::max(1L, std::min(want, (long)c->num_cus * bpc));
-    const bool sorted = c->kernel == 2 && c->schedule == 1 && c->spp_per_launch == 0 && max_samples >= 4 * c->prepass_spp && max_samples <= 65535;
+    int pre = c->prepass_spp > 0 ? c->prepass_spp : 8; // samples of the cost pre-pass
+    const bool sorted = c->kernel == 2 && c->schedule == 1 && c->spp_per_launch == 0 && max_samples >= 4 * pre && max_samples <= 65535;
     // Whole-pixel schedule (pt_kernel.hip, TIERS): when every pixel can have a path slot from the start, the main launch hands out
     // pixels instead of (pixel, chunk) tickets, and every wave serves one cost class with as few pixels as that class needs - the plan
     // is made on the device from the histogram of the counting sort (pt_plan_tiers_kernel).  Option "whole": -1 automatic, 0 never.
@@ -675,7 +676,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     if (sorted && P.nodes8 && c->whole != 0 && c->slots_per_wave == 0 && occ > 0) {
         const long capacity = (long)c->num_cus * bpc;
         for (int nsd = 96; nsd <= 104 && !tiers; nsd += 8) { // 16 waves per CU up to 104 slots
-            if ((long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
+            if (c->whole < 1 && (long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
             want_ns = nsd;
             HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
             if (occ >= bpc && ns == nsd) {
@@ -689,6 +690,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
+    // the tier plan lives on the cost estimate: twice the samples (1/8 shard of C4 218 -> 201 ms; a throughput-bound frame gains nothing)
+    if (tiers && c->prepass_spp == 0 && max_samples >= 4 * 16) pre = 16;
     uint32_t n_express = 0;
     int express_waves = 0;
     if (state_words) {
@@ -734,7 +737,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         S = max_samples;
         n_launch = sorted ? 2 : 1;
         if (sorted) {
-            const int rest = max_samples - c->prepass_spp;
+            const int rest = max_samples - pre;
             // Share of a pixel's remaining samples that its first slot renders in one go.  With many more pixels than slots the
             // frame is throughput-bound and hand-offs are pure overhead: 75 %.  With all pixels in flight from the start (small
             // images, one shard of eight) the frame is the longest pixels' sample chains, and every hand-off moves such a chain
@@ -851,8 +854,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.sample_begin = l * S;
         P.sample_count = std::min(S, max_samples - l * S);
         if (sorted) { // launch 0: cost pre-pass in queue order; launch 1: everything else, expensive pixels first
-            P.sample_begin = l == 0 ? 0 : c->prepass_spp;
-            P.sample_count = l == 0 ? c->prepass_spp : max_samples - c->prepass_spp;
+            P.sample_begin = l == 0 ? 0 : pre;
+            P.sample_count = l == 0 ? pre : max_samples - pre;
             P.pixel_ids = l == 0 ? (const uint32_t*)c->d_pixels.p : (const uint32_t*)c->d_sorted.p;
             P.cost_out = l == 0 ? (uint8_t*)c->d_cost.p : nullptr;
             P.dbg_start = (l == 1 && c->latency) ? (uint32_t*)c->d_dbg_start.p : nullptr;
@@ -880,7 +883,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             }
             if (l == 1) {
                 HIP_TRY(c, pt_launch_sort_pixels((const uint8_t*)c->d_cost.p, W, H, c->cost_radius, (const uint32_t*)c->d_pixels.p, (uint32_t*)c->d_sorted.p,
-                                                 c->n_pixels, (uint32_t)c->prepass_spp, (uint32_t*)c->d_sort_scratch.p, (uint8_t*)c->d_bucket.p, stream));
+                                                 c->n_pixels, (uint32_t)pre, (uint32_t*)c->d_sort_scratch.p, (uint8_t*)c->d_bucket.p, stream));
                 if (tiers) HIP_TRY(c, pt_launch_plan_tiers((const uint32_t*)c->d_sort_scratch.p, c->n_pixels, grid, ns, c->whole > 0, (uint32_t*)c->d_tiers.p, stream));
                 HIP_TRY(c, hipEventRecord(c->evm, stream));
             }
@@ -901,6 +904,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     c->stats.kernel_variant = variant;
     c->stats.express_pixels = n_express;
     c->stats.whole_pixels = tiers ? (int32_t)c->n_pixels : 0;
+    c->stats.prepass_spp = sorted ? pre : 0;
     c->stats.sgprs = sg;
     c->stats.lds_bytes = (int)lds + slds;
     c->stats.block = block;

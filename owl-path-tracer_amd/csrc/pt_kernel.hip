@@ -1853,6 +1853,19 @@ __device__ __forceinline__ int tier_pixels(float rays, float T, int ns)
     if (rays * tier_turnaround(ns) <= T) best = ns;
     return best;
 }
+// Workgroups for the `cnt` pixels of a class whose chain takes `t`: `per` pixels per wave (tier_pixels), and when a pixel of the class
+// is done well before T its slot takes another one of the class (take_ticket) - as many rounds as fit.
+__device__ __forceinline__ uint32_t tier_waves(uint32_t cnt, float t, float T, int ns, int* per_out)
+{
+    const int per = tier_pixels(t, T, ns);
+    const float one = t * tier_turnaround(per);
+    uint32_t rounds = one < T ? (uint32_t)(T / one) : 1u;
+    if (rounds < 1u) rounds = 1u;
+    if (rounds > 1024u) rounds = 1024u;
+    if (per_out) *per_out = per;
+    const uint32_t slots = (uint32_t)per * rounds;
+    return (cnt + slots - 1u) / slots;
+}
 // One thread.  block_off: the scanned histogram of the sort (bucket b starts at queue entry block_off[b * nb]).  The frame time is the
 // largest chain x turnaround over the classes; bisect the smallest T whose plan fits the `capacity` resident waves.
 // The plan pays when the frame has a tail: a cheap majority and an expensive minority whose chains decide when it ends (a shard of the
@@ -1871,15 +1884,14 @@ __global__ void pt_plan_tiers_kernel(const uint32_t* __restrict__ block_off, uin
         while (b50 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b50 + 1] * 2ull < (unsigned long long)n) ++b50;
         if (b50 - b98 < PT_TIER_MIN_SPREAD) { tiers[0] = 0u; return; }
     }
-    float lo = 0.0f, hi = bucket_time(0) * tier_turnaround(ns) * 1.01f; // at hi every class runs ns pixels per wave
-    for (int it = 0; it < 20; ++it) {
+    // at hi every class runs ns pixels per wave, in as many rounds as the pixels need
+    float lo = 0.0f, hi = bucket_time(0) * tier_turnaround(ns) * (2.0f + 2.0f * (float)n / ((float)capacity * (float)ns));
+    for (int it = 0; it < 24; ++it) {
         const float T = 0.5f * (lo + hi);
         long waves = 0;
         for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
             const uint32_t cnt = start[b + 1] - start[b];
-            if (cnt == 0u) continue;
-            const int per = tier_pixels(bucket_time(b), T, ns);
-            waves += (long)((cnt + (uint32_t)per - 1u) / (uint32_t)per);
+            if (cnt != 0u) waves += (long)tier_waves(cnt, bucket_time(b), T, ns, nullptr);
         }
         if (waves <= (long)capacity) hi = T; else lo = T;
     }
@@ -1887,8 +1899,8 @@ __global__ void pt_plan_tiers_kernel(const uint32_t* __restrict__ block_off, uin
     for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
         const uint32_t cnt = start[b + 1] - start[b];
         if (cnt == 0u) continue;
-        const int per = tier_pixels(bucket_time(b), hi, ns);
-        const uint32_t w = (cnt + (uint32_t)per - 1u) / (uint32_t)per;
+        int per = 0;
+        const uint32_t w = tier_waves(cnt, bucket_time(b), hi, ns, &per);
         uint32_t* e = tiers + 1 + PT_TIER_WORDS * n_tiers;
         e[0] = start[b]; e[1] = cnt; e[2] = (uint32_t)per; e[3] = wave; e[4] = w; e[5] = (uint32_t)b; e[6] = 0u; e[7] = 0u;
         wave += w;
