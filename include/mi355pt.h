@@ -185,7 +185,10 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   6x faster to build, 1.25x slower to walk) | 2 (PLOC on the device: 3x faster to build, 1.08x slower to walk; "ploc_radius" 16; a tree
  *   deeper than max_bvh_depth falls back to 0);  "blocks_per_cu", "slots_per_wave": launch geometry;
  *   "schedule" 1 (default: cost pre-pass + cost-ordered queue, from 4 x prepass_spp samples per pixel) | 0 (chunks only);
- *   "prepass_spp" (8), "cost_radius" (2: cost = maximum over the (2r+1)^2 neighbourhood), "sticky_pct" (automatic, 10-75: share of the
+ *   "prepass_spp" (0 = automatic: 8, or 16 when a tier plan is prepared), "cost_radius" (2: the cost of a pixel - the time its pre-pass
+ *   samples took - is de-noised by the mean over the look-alike pixels of its (2r+1)^2 neighbourhood), "whole" -1 (default: a launch
+ *   whose pixels can all have a path slot from the start hands out whole pixels by cost class if a plan made on the device says so)
+ *   | 0 (never: ring schedule) | 1 (always), "sticky_pct" (automatic, 10-75: share of the
  *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (16: smallest of the
  *   halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
  *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build;
@@ -226,8 +229,8 @@ int pt_debug_quad_info(pt_ctx* ctx, int64_t out[8]);
 int pt_debug_oct_info(pt_ctx* ctx, int64_t out[8]);
 
 /* The pixel queue of the last pt_render* call with the cost-ordered schedule: queue_ids[i] = pixel id (x + width * y) of
- * entry i of the cost-ordered queue, input_ids[i] / cost[i] = entry i of the shard's input queue and the rays its first
- * prepass_spp samples traced (saturating at 255).  Any pointer may be NULL.  Returns the number of entries (0: the last
+ * entry i of the cost-ordered queue, input_ids[i] / cost[i] = entry i of the shard's input queue and its cost class: 16 log2 of
+ * the microseconds its first prepass_spp samples took (1..255).  Any pointer may be NULL.  Returns the number of entries (0: the last
  * render did not sort), or a negative error. */
 int64_t pt_debug_read_queue(pt_ctx* ctx, uint32_t* queue_ids, uint32_t* input_ids, uint8_t* cost, int64_t cap);
 

@@ -133,14 +133,16 @@ def main():
                          "cycle_share": round(g[6] / max(1, cyc["total"]), 4), "cycles/iter": round(g[6] / max(1, g[1]), 1)}
         print(json.dumps(cen))
     if opts.get("chain"):
-        # per-ray turnaround of the longest sample chain: the cost pre-pass counted the rays of the first 8 samples of every pixel
-        # (saturating at 255), so the most expensive pixel traces about max_cost / 8 * spp sequential rays in kernel_ms
-        _, _, cost = ctx.read_queue(W * H)
-        if cost.size:
-            mx = int(cost.max()); p999 = float(np.percentile(cost, 99.9))
-            print(json.dumps({"chain": {"max_cost_per_8spp": mx, "p99.9_cost": p999, "longest_chain_rays": int(mx / 8 * spp),
-                                        "us_per_ray_longest_chain": round(min(ms) * 1e3 / max(1.0, mx / 8 * spp), 2),
-                                        "us_per_ray_p99.9_chain": round(min(ms) * 1e3 / max(1.0, p999 / 8 * spp), 2)}}))
+        # per-ray turnaround of the longest sample chain: one more render that counts the rays of every pixel (latency=1)
+        ctx.set_option("latency", 1)
+        ctx.render(cam, W, H, spp, 16)
+        fin, nrays = ctx.read_finish(W * H)
+        ctx.set_option("latency", 0)
+        if nrays.size and nrays.any():
+            mx = int(nrays.max()); p999 = float(np.percentile(nrays[nrays > 0], 99.9)); last = int(np.argmax(fin))
+            print(json.dumps({"chain": {"longest_chain_rays": mx, "p99.9_chain_rays": int(p999), "us_per_ray_longest_chain": round(min(ms) * 1e3 / max(1, mx), 2),
+                                        "us_per_ray_p99.9_chain": round(min(ms) * 1e3 / max(1.0, p999), 2),
+                                        "last_pixel(rays,ms)": (int(nrays[last]), round(float(fin[last]), 1)), "tiers": len(ctx.read_tiers()), "prepass_spp": ctx.stats().get("prepass_spp", 0)}}))
     if opts.get("timeline"):
         print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
