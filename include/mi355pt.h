@@ -189,8 +189,8 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   samples took - is de-noised by the mean over the look-alike pixels of its (2r+1)^2 neighbourhood), "whole" -1 (default: a launch
  *   whose pixels can all have a path slot from the start hands out whole pixels by cost class if a plan made on the device says so)
  *   | 0 (never: ring schedule) | 1 (always), "sticky_pct" (automatic, 10-75: share of the
- *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (16: smallest of the
- *   halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
+ *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (-1 = automatic: an eighth of the
+ *   samples after the pre-pass, at least 16: smallest of the halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
  *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build;
  *   "groups" 1 (default: a wave with few rays to trace walks them eight lanes per ray over oct nodes) | 0 (never) | 2 (always: tests),
  *   "wide_leaves" 1 (oct nodes: subtrees of <= 7 triangles are one leaf step; next pt_upload_scene), "tune6" / "tune7" (16 / 24: ray-queue

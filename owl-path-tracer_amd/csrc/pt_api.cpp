@@ -284,7 +284,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "census_mode") c->census_mode = (int)value;
     else if (k == "schedule") c->schedule = value == 0 ? 0 : 1;
     else if (k == "prepass_spp") c->prepass_spp = (int)(value < 0 ? 0 : (value > 64 ? 64 : value)); // 0: automatic (8; 16 when a tier plan is prepared)
-    else if (k == "chunk_tail_min") c->chunk_tail_min = (int)(value < 0 ? 0 : (value > 65535 ? 65535 : value));
+    else if (k == "chunk_tail_min") c->chunk_tail_min = (int)(value < 0 ? -1 : (value > 65535 ? 65535 : value)); // -1: automatic
     else if (k == "chunk_spp") c->chunk_spp = (int)(value < 1 ? 1 : (value > 65535 ? 65535 : value));
     else if (k == "slots_per_wave") c->slots_per_wave = (int)(value < 0 ? 0 : value);
     else if (k == "adaptive") c->tune[5] = value ? 1 : 2;
@@ -704,16 +704,17 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // halving chunks (rem/2, rem/4, ... >= chunk_tail_min).  A frame ends when its slowest in-flight work item ends, so the
     // last items must be short (profiles/r01_summary.md, "wind-down").
     struct Schedule { int chunk = 0, n_full = 0, n_chunks = 1, tail_len[PT_MAX_TAIL_CHUNKS] = {}; };
+    int tail_min = c->chunk_tail_min >= 0 ? c->chunk_tail_min : 16; // smallest chunk of the halving tail (automatic: set per schedule below)
     auto make_schedule = [&](int total, int chunk, int rem_min) {
         Schedule sc;
         sc.chunk = std::max(1, std::min(chunk, total));
         sc.n_full = total / sc.chunk;
         int rem = total - sc.n_full * sc.chunk;
-        if (c->chunk_tail_min > 0 && sc.n_full > 0 && rem < rem_min) { --sc.n_full; rem += sc.chunk; }
+        if (tail_min > 0 && sc.n_full > 0 && rem < rem_min) { --sc.n_full; rem += sc.chunk; }
         int n_tail = 0;
         while (rem > 0) {
             int len = rem;
-            if (c->chunk_tail_min > 0 && rem > c->chunk_tail_min && n_tail < PT_MAX_TAIL_CHUNKS - 1) len = std::max(c->chunk_tail_min, (rem + 1) / 2);
+            if (tail_min > 0 && rem > tail_min && n_tail < PT_MAX_TAIL_CHUNKS - 1) len = std::max(tail_min, (rem + 1) / 2);
             sc.tail_len[n_tail++] = len;
             rem -= len;
         }
@@ -749,6 +750,10 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 const double ratio = (double)c->n_pixels / ((double)c->num_cus * (double)bpc * (double)ns);
                 sticky = (int)std::min(75.0, std::max(10.0, 20.0 * ratio));
             }
+            // With the queue ordered by the TIME of a pixel's samples the hand-offs of the tail buy little and every lap is a barrier of
+            // sorts: the last quarter goes in two chunks, not five (C4 528 -> 500 ms, C3 161 -> 153; smallest tail chunk 16 / 32 / 64 / 128
+            // of 1016 samples: 528 / 515 / 505 / 498 ms; profiles/r03_logs/r3_ab54.log).
+            if (c->chunk_tail_min < 0) tail_min = std::max(16, rest / 8);
             const int big = std::max(1, (int)((int64_t)rest * sticky / 100));
             main_sc = make_schedule(rest, big, rest - big);
             if ((rc = ensure(c, c->d_cost, (size_t)W * H))) return rc; // cost image; zero where this rank owns nothing

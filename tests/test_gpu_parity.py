@@ -375,7 +375,7 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     assert gpu.stats()["launches"] == 1
     gpu.set_option("chunk_tail_min", 0)
     ring_fixed, _ = gpu.render(cam, W, H, 70, 16)
-    gpu.set_option("chunk_tail_min", 8)
+    gpu.set_option("chunk_tail_min", -1)
     gpu.set_option("chunk_spp", 64)
     gpu.set_option("schedule", 1)
     assert_bitwise(ring, by_cost, "FIFO ring == cost-ordered queue")
@@ -390,7 +390,7 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
             gpu.set_option(k, v)
         got, _ = gpu.render(cam, W, H, spp, 16)
         assert gpu.stats()["launches"] == 2, (spp, opts)
-        for k, v in {"sticky_pct": 75, "chunk_tail_min": 16, "prepass_spp": 0, "cost_radius": 2, "slots_per_wave": 0}.items():
+        for k, v in {"sticky_pct": 75, "chunk_tail_min": -1, "prepass_spp": 0, "cost_radius": 2, "slots_per_wave": 0}.items():
             gpu.set_option(k, v)
         want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, spp, 16)
         assert_bitwise(got, want, "schedule %r at %d spp" % (opts, spp))
