@@ -740,15 +740,13 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         if (sorted) {
             const int rest = max_samples - pre;
             // Share of a pixel's remaining samples that its first slot renders in one go.  With many more pixels than slots the
-            // frame is throughput-bound and hand-offs are pure overhead: 75 %.  With all pixels in flight from the start (small
-            // images, one shard of eight) the frame is the longest pixels' sample chains, and every hand-off moves such a chain
-            // out of the wave it shares with its (equally expensive) neighbours into whatever wave has idle slots: 10-25 %.
-            // Measured on C4 (ms; pixels / slots = 0.66, 1.3, 2.6, 5.3): 10 %: 380 430 511 -, 25 %: 387 438 494 650,
-            // 50 %: 408 435 486 633, 75 %: 470 485 504 608.
+            // frame is throughput-bound and hand-offs are pure overhead: 80 %; with fewer pixels per slot 50-65 % (a launch whose
+            // pixels all have a slot and whose costs have a tail runs the tier schedule instead).
             int sticky = c->sticky_pct;
             if (sticky < 1) {
                 const double ratio = (double)c->n_pixels / ((double)c->num_cus * (double)bpc * (double)ns);
-                sticky = (int)std::min(75.0, std::max(10.0, 20.0 * ratio));
+                sticky = (int)std::min(80.0, 50.0 + 6.0 * ratio); // (rounds 1-2, queue ordered by rays: 10-75, rising with the ratio; re-swept with the
+                                                                 // queue ordered by time: C4 80, 1/2 shard and C3 65, 1/4 shard 50-65, C2 60 - r3_ab57/58.log)
             }
             // With the queue ordered by the TIME of a pixel's samples the hand-offs of the tail buy little and every lap is a barrier of
             // sorts: the last quarter goes in two chunks, not five (C4 528 -> 500 ms, C3 161 -> 153; smallest tail chunk 16 / 32 / 64 / 128
