@@ -1878,7 +1878,7 @@ __global__ void pt_plan_tiers_kernel(const uint32_t* __restrict__ block_off, uin
     uint32_t start[PT_SORT_BUCKETS + 1];
     for (int b = 0; b < PT_SORT_BUCKETS; ++b) start[b] = block_off[(size_t)b * nb];
     start[PT_SORT_BUCKETS] = n;
-    if (!force) {
+    if (!force && (unsigned long long)n > 16ull * (unsigned long long)capacity) { // (a launch with <= 16 pixels per resident wave always: the ring schedule would run it in a few dense waves)
         int b98 = 0, b50 = 0;
         while (b98 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b98 + 1] * 50ull < (unsigned long long)n) ++b98;
         while (b50 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b50 + 1] * 2ull < (unsigned long long)n) ++b50;

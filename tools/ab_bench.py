@@ -146,7 +146,7 @@ def main():
     if opts.get("timeline"):
         print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
-                      "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
+                      "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "prepass_ms": round(st.get("prepass_ms", 0.0), 2), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
                       "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": round(st["bvh_build_ms"], 2)}))
 
 main()
