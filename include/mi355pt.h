@@ -250,6 +250,12 @@ int64_t pt_debug_read_finish(pt_ctx* ctx, uint32_t* ticks, int64_t cap);
  * words written (at most 257), 0 if the last render used the ring schedule. */
 int64_t pt_debug_read_tiers(pt_ctx* ctx, uint32_t* words, int64_t cap);
 
+/* The tier plan for a launch whose cost-ordered queue holds bucket_pixels[b] pixels in cost bucket b (32 buckets, 0 = most expensive,
+ * each 19 % cheaper than the one before), with `capacity` resident workgroups and `ns` path slots per wave: exactly what the device
+ * computes after the counting sort, run on the host (no GPU needed).  force = 1: plan even when the cost distribution has no tail.
+ * Same output as pt_debug_read_tiers (words[0] = 0: the plan declines and the launch runs the ring schedule); cap >= 257. */
+int64_t pt_debug_plan_tiers(const uint32_t* bucket_pixels, int32_t capacity, int32_t ns, int32_t force, uint32_t* words, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "pt_internal.h"
+#include "pt_tiers.h"
 
 extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
                                        hipStream_t stream, int count);
@@ -1144,6 +1145,19 @@ int64_t pt_debug_read_laps(pt_ctx* c, uint64_t* ticks, int64_t cap)
     for (int i = 0; i < nt && n < cap; ++i) ticks[n++] = blk[(size_t)i];
     for (int i = 0; i < 64 && n < cap; ++i) ticks[n++] = blk[(size_t)PT_LAP_DIAG_OFS(c->last_chunks) + i];
     return n;
+}
+
+int64_t pt_debug_plan_tiers(const uint32_t* bucket_pixels, int32_t capacity, int32_t ns, int32_t force, uint32_t* words, int64_t cap)
+{
+    if (!bucket_pixels || !words || capacity < 1 || ns < 4 || ns > 255 || cap < 1 + PT_MAX_TIERS * PT_TIER_WORDS) return PT_E_INVALID;
+    uint32_t start[PT_SORT_BUCKETS + 1];
+    uint64_t run = 0;
+    for (int b = 0; b < PT_SORT_BUCKETS; ++b) { start[b] = (uint32_t)run; run += bucket_pixels[b]; }
+    if (run == 0 || run >= (1ull << 31)) return PT_E_INVALID;
+    start[PT_SORT_BUCKETS] = (uint32_t)run;
+    std::memset(words, 0, (size_t)(1 + PT_MAX_TIERS * PT_TIER_WORDS) * 4);
+    pt_plan_tiers(start, capacity, ns, force, words); // the code of pt_plan_tiers_kernel, on the host
+    return 1 + (int64_t)words[0] * PT_TIER_WORDS;
 }
 
 int64_t pt_debug_read_tiers(pt_ctx* c, uint32_t* words, int64_t cap)

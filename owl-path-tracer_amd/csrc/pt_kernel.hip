@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "pt_device.h"
+#include "pt_tiers.h"
 #include "pt_types.h"
 
 using namespace ptd;
@@ -1734,7 +1735,6 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
 // the expensive pixels first (stable counting sort over PT_SORT_BUCKETS cost classes, so neighbours stay neighbours).
 #define PT_SORT_BLOCK 256
 #define PT_SORT_ITEMS 16
-#define PT_SORT_BUCKETS 32
 
 // Cost of a pixel for the ordering and the tier plan: the class the pre-pass recorded for it (pt_cost_class), de-noised.  A few
 // samples are a noisy estimate, and a pixel that is taken for cheaper than it is spends the frame in a wave that is too dense for it
@@ -1765,15 +1765,11 @@ __device__ __forceinline__ uint32_t pixel_cost(const uint8_t* __restrict__ img, 
 
 // Cost classes of the queue: PT_SORT_BUCKETS buckets of four pre-pass classes each (19 % wide), from class PT_COST_TOP (20 ms for the
 // pre-pass's samples of one pixel) down; everything below 80 us shares the last bucket.  0 = most expensive.
-#define PT_COST_TOP 230
-#define PT_TIER_MIN_SPREAD 6 // buckets between the median pixel and the 98th percentile (2.8x in time) from which the tier plan is used
 __device__ __forceinline__ int cost_bucket(uint32_t cls)
 {
     const int b = (PT_COST_TOP - (int)cls) / 4;
     return b < 0 ? 0 : (b > PT_SORT_BUCKETS - 1 ? PT_SORT_BUCKETS - 1 : b);
 }
-// relative sample-chain duration of a pixel in `bucket`: the middle of the bucket
-__device__ __forceinline__ float bucket_time(int bucket) { return exp2f(((float)(PT_COST_TOP - 4 * bucket) - 1.5f) * 0.0625f); }
 
 __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_hist_kernel(const uint8_t* __restrict__ img, const uint32_t* __restrict__ in, int W, int H, int R, uint32_t n,
                                                                     uint32_t c0, uint32_t* __restrict__ block_hist, uint8_t* __restrict__ bucket)
@@ -1827,86 +1823,15 @@ __global__ void __launch_bounds__(PT_SORT_BLOCK) pt_sort_scatter_kernel(const ui
     for (uint32_t i = first; i < first + PT_SORT_ITEMS && i < n; ++i) out[cnt[bucket[i]][t]++] = in[i];
 }
 
-// ---- tier plan of the whole-pixel schedule (take_ticket) --------------------------------------------------------------------
-// Turnaround of a ray in a wave that holds n pixels, relative to a wave with 96: measured on a 1/8 shard of C4 with waves that hold
-// nothing but expensive pixels (profiles/r03_logs/r3_ab37.log: 25 / 28 / 35 / 43 / 56 / 48 / 49 us at 4 / 8 / 12 / 16 / 24 / 32 / 48 pixels,
-// 60-66 at 96).  Between 16 and 32 pixels a wave is neither: too many rays for the group walk (three phases in a row), too few for
-// the per-lane walk - the plan never uses 17..31.
-__device__ __forceinline__ float tier_turnaround(int n)
-{
-    const float xs[9] = {4.f, 8.f, 12.f, 16.f, 32.f, 48.f, 64.f, 96.f, 128.f};
-#ifndef PT_TIER_CURVE
-#define PT_TIER_CURVE 0.33f, 0.38f, 0.46f, 0.52f, 0.68f, 0.78f, 0.86f, 1.0f, 1.1f
-#endif
-    const float ys[9] = {PT_TIER_CURVE};
-    if (n <= 4) return ys[0];
-    for (int i = 1; i < 9; ++i)
-        if ((float)n <= xs[i]) return ys[i - 1] + (ys[i] - ys[i - 1]) * ((float)n - xs[i - 1]) / (xs[i] - xs[i - 1]);
-    return ys[8];
-}
-// pixels per wave for a class whose chain is `rays` long if the frame is to end at `T` (relative units): the most that still make it
-__device__ __forceinline__ int tier_pixels(float rays, float T, int ns)
-{
-    int best = 4;
-    for (int n = 4; n <= ns; n += (n < 16 ? 2 : (n == 16 ? 16 : 8))) // 4 6 .. 16, 32 40 .. ns
-        if (rays * tier_turnaround(n) <= T) best = n;
-    if (rays * tier_turnaround(ns) <= T) best = ns;
-    return best;
-}
-// Workgroups for the `cnt` pixels of a class whose chain takes `t`: `per` pixels per wave (tier_pixels), and when a pixel of the class
-// is done well before T its slot takes another one of the class (take_ticket) - as many rounds as fit.
-__device__ __forceinline__ uint32_t tier_waves(uint32_t cnt, float t, float T, int ns, int* per_out)
-{
-    const int per = tier_pixels(t, T, ns);
-    const float one = t * tier_turnaround(per);
-    uint32_t rounds = one < T ? (uint32_t)(T / one) : 1u;
-    if (rounds < 1u) rounds = 1u;
-    if (rounds > 1024u) rounds = 1024u;
-    if (per_out) *per_out = per;
-    const uint32_t slots = (uint32_t)per * rounds;
-    return (cnt + slots - 1u) / slots;
-}
-// One thread.  block_off: the scanned histogram of the sort (bucket b starts at queue entry block_off[b * nb]).  The frame time is the
-// largest chain x turnaround over the classes; bisect the smallest T whose plan fits the `capacity` resident waves.
-// The plan pays when the frame has a tail: a cheap majority and an expensive minority whose chains decide when it ends (a shard of the
-// dragon: the 98th percentile pixel takes ~10x the median pixel's time).  When all pixels cost about the same (the Cornell box: 1.4x)
-// homogeneous waves gain nothing over the ring schedule, which balances the waves' load chunk by chunk (C2: 75 vs 85 ms): unless
-// `force`, the table is then left empty and the launch runs the ring schedule the host prepared alongside.
+// ---- tier plan of the whole-pixel schedule (take_ticket): pt_tiers.h ----------------------------------------------------------
+// One thread.  block_off: the scanned histogram of the sort (bucket b starts at queue entry block_off[b * nb]).
 __global__ void pt_plan_tiers_kernel(const uint32_t* __restrict__ block_off, uint32_t nb, uint32_t n, int capacity, int ns, int force, uint32_t* __restrict__ tiers)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t start[PT_SORT_BUCKETS + 1];
     for (int b = 0; b < PT_SORT_BUCKETS; ++b) start[b] = block_off[(size_t)b * nb];
     start[PT_SORT_BUCKETS] = n;
-    if (!force && (unsigned long long)n > 16ull * (unsigned long long)capacity) { // (a launch with <= 16 pixels per resident wave always: the ring schedule would run it in a few dense waves)
-        int b98 = 0, b50 = 0;
-        while (b98 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b98 + 1] * 50ull < (unsigned long long)n) ++b98;
-        while (b50 < PT_SORT_BUCKETS - 1 && (unsigned long long)start[b50 + 1] * 2ull < (unsigned long long)n) ++b50;
-        if (b50 - b98 < PT_TIER_MIN_SPREAD) { tiers[0] = 0u; return; }
-    }
-    // at hi every class runs ns pixels per wave, in as many rounds as the pixels need
-    float lo = 0.0f, hi = bucket_time(0) * tier_turnaround(ns) * (2.0f + 2.0f * (float)n / ((float)capacity * (float)ns));
-    for (int it = 0; it < 24; ++it) {
-        const float T = 0.5f * (lo + hi);
-        long waves = 0;
-        for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
-            const uint32_t cnt = start[b + 1] - start[b];
-            if (cnt != 0u) waves += (long)tier_waves(cnt, bucket_time(b), T, ns, nullptr);
-        }
-        if (waves <= (long)capacity) hi = T; else lo = T;
-    }
-    uint32_t n_tiers = 0, wave = 0;
-    for (int b = 0; b < PT_SORT_BUCKETS; ++b) {
-        const uint32_t cnt = start[b + 1] - start[b];
-        if (cnt == 0u) continue;
-        int per = 0;
-        const uint32_t w = tier_waves(cnt, bucket_time(b), hi, ns, &per);
-        uint32_t* e = tiers + 1 + PT_TIER_WORDS * n_tiers;
-        e[0] = start[b]; e[1] = cnt; e[2] = (uint32_t)per; e[3] = wave; e[4] = w; e[5] = (uint32_t)b; e[6] = 0u; e[7] = 0u;
-        wave += w;
-        ++n_tiers;
-    }
-    tiers[0] = n_tiers;
+    pt_plan_tiers(start, capacity, ns, force, tiers);
 }
 
 extern "C" hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream)

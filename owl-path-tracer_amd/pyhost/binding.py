@@ -62,7 +62,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_upload_scene", "pt_set_materials", "pt_set_environment",
            "pt_set_pixel_shard", "pt_shard_pixels", "pt_render", "pt_render_device", "pt_synchronize", "pt_set_option", "pt_get_stats",
-           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps", "pt_debug_read_finish", "pt_debug_read_tiers",
+           "pt_to_camera_data", "pt_debug_closest_hit_host", "pt_debug_eval", "pt_debug_read_queue", "pt_debug_read_laps", "pt_debug_read_finish", "pt_debug_read_tiers", "pt_debug_plan_tiers",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_framebuffer", "pt_host_alloc", "pt_host_free",
            "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_ctx", "pt_group_last_error", "pt_group_upload_scene",
            "pt_group_set_materials", "pt_group_set_option", "pt_group_render", "pt_debug_quad_info", "pt_debug_oct_info", "pt_debug_clone_scene"]
@@ -110,6 +110,8 @@ def lib():
     L.pt_debug_read_finish.restype = C.c_int64
     L.pt_debug_read_tiers.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
     L.pt_debug_read_tiers.restype = C.c_int64
+    L.pt_debug_plan_tiers.argtypes = [C.POINTER(C.c_uint32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]
+    L.pt_debug_plan_tiers.restype = C.c_int64
     u8p = C.POINTER(C.c_uint8)
     L.pt_comm_get_unique_id.argtypes = [u8p]
     L.pt_comm_init_rank.argtypes = [C.c_void_p, u8p, C.c_int32, C.c_int32]
@@ -211,6 +213,17 @@ def make_env(use_map=False, use_auto=False, color=(0, 0, 0), intensity=0.0, env_
     e.intensity = float(intensity)
     e.map, e._keep = _texture(env_map)
     return e
+
+
+def plan_tiers(bucket_pixels, capacity, ns=96, force=False):
+    """The device's tier plan (pt_tiers.h) for a cost histogram of 32 buckets, run on the host: list of dicts as Context.read_tiers()."""
+    h = np.ascontiguousarray(bucket_pixels, np.uint32)
+    assert h.size == 32
+    t = np.zeros(257, np.uint32)
+    n = lib().pt_debug_plan_tiers(h.ctypes.data_as(C.POINTER(C.c_uint32)), int(capacity), int(ns), int(bool(force)), t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size)
+    if n < 0:
+        raise RuntimeError("pt_debug_plan_tiers: %d" % n)
+    return [dict(zip(("q0", "pixels", "per_wave", "wave0", "waves", "cost_class"), (int(x) for x in t[1 + 8 * i:7 + 8 * i]))) for i in range(int(t[0]))]
 
 
 class Context:

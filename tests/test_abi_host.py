@@ -195,3 +195,62 @@ def test_rccl_load_failure_is_an_error_code_not_a_crash(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def _check_tiers(tiers, hist, capacity, ns):
+    """Invariants of a tier table: consecutive queue ranges that cover every pixel, one tier per non-empty bucket in bucket order,
+    workgroup ranges one after the other within the resident waves, pixels per wave from the plan's menu, waves that are needed."""
+    menu = set(range(4, 17, 2)) | set(range(32, ns + 1, 8)) | {ns}
+    q0 = w0 = 0
+    assert [t["cost_class"] for t in tiers] == [b for b in range(32) if hist[b]]
+    for t in tiers:
+        assert t["q0"] == q0 and t["pixels"] == hist[t["cost_class"]] and t["wave0"] == w0
+        assert t["per_wave"] in menu and t["waves"] >= 1
+        assert (t["waves"] - 1) * t["per_wave"] < t["pixels"]  # no workgroup without a pixel
+        q0 += t["pixels"]
+        w0 += t["waves"]
+    assert q0 == int(np.sum(hist)) and w0 <= capacity
+
+
+def test_tier_plan_on_the_host():
+    """pt_tiers.h - the plan a one-thread kernel makes on the device after the counting sort - run on the host (pt_debug_plan_tiers):
+    a frame with a tail gets sparse waves for its expensive buckets and dense ones for the cheap majority, within the resident waves;
+    a frame whose pixels all cost the same is left to the ring schedule unless forced; a very sparse launch always gets a plan; a
+    launch with more pixels than slots fits by rounds."""
+    cap, ns = 4096, 96
+    # a shard of the dragon (1/8 of C4, roughly): 28 % sky, 45 % floor, the rest spread over 14 ever more expensive buckets
+    hist = np.zeros(32, np.uint32)
+    hist[31] = 72000; hist[26:29] = (21000, 33000, 25000); hist[19:26] = (7700, 9200, 10400, 9800, 8400, 8500, 10800)
+    hist[10:19] = (50, 740, 2500, 3500, 4300, 6000, 8500, 8900, 8000)
+    tiers = B.plan_tiers(hist, cap, ns)
+    assert tiers, "a distribution with a tail must be planned"
+    _check_tiers(tiers, hist, cap, ns)
+    per = {t["cost_class"]: t["per_wave"] for t in tiers}
+    assert per[10] <= 8 and per[31] == ns  # the longest chains in group-walk waves, the sky pixels in full ones
+    assert all(per[a] <= per[b] for a, b in zip(sorted(per), sorted(per)[1:])), "cheaper buckets never get sparser waves"
+    assert sum(t["waves"] for t in tiers) > 0.9 * cap  # the plan spends the waves it has
+    # the same shape, eight times the pixels (the whole frame): does not fit one round - the plan uses rounds and still fits
+    big = B.plan_tiers(hist * 8, cap, ns, force=True)
+    _check_tiers(big, hist * 8, cap, ns)
+    assert sum(t["waves"] * t["per_wave"] for t in big) < int(hist.sum()) * 8  # fewer slots than pixels: slots are reused
+    # every pixel in two neighbouring buckets (a Cornell box): no tail -> the ring schedule (empty table) unless forced
+    flat = np.zeros(32, np.uint32)
+    flat[12:14] = (130000, 130000)
+    assert B.plan_tiers(flat, cap, ns) == []
+    forced = B.plan_tiers(flat, cap, ns, force=True)
+    _check_tiers(forced, flat, cap, ns)
+    # at most 16 pixels per resident wave: always planned, and nobody needs a dense wave
+    sparse = np.zeros(32, np.uint32)
+    sparse[12:14] = (16000, 16000)
+    tiers = B.plan_tiers(sparse, cap, ns)
+    _check_tiers(tiers, sparse, cap, ns)
+    assert max(t["per_wave"] for t in tiers) <= 16
+    # one pixel, one wave
+    one = np.zeros(32, np.uint32)
+    one[0] = 1
+    tiers = B.plan_tiers(one, cap, ns)
+    assert len(tiers) == 1 and tiers[0]["waves"] == 1 and tiers[0]["per_wave"] == 4
+    # bad arguments are refused
+    t = np.zeros(257, np.uint32)
+    assert B.lib().pt_debug_plan_tiers(one.ctypes.data_as(C.POINTER(C.c_uint32)), 0, 96, 0, t.ctypes.data_as(C.POINTER(C.c_uint32)), 257) < 0
+    assert B.lib().pt_debug_plan_tiers(one.ctypes.data_as(C.POINTER(C.c_uint32)), 4096, 96, 0, t.ctypes.data_as(C.POINTER(C.c_uint32)), 16) < 0
