@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
         if (n_tiers == 0u) { // the plan chose the ring schedule (pt_plan_tiers_kernel): the launch has more workgroups than that wants
             if (blockIdx.x >= (uint32_t)P.ring_grid) ns_live = 0;
         } else {
-        ns_live = 1; // a workgroup beyond the plan finds its (null) tier empty and ends
+        ns_live = 0; // a workgroup beyond the plan has nothing to do and must not touch a tier's counter
         w.tier.counter = P.queue_head + PT_TIER_COUNTER(0);
         for (uint32_t t = 0; t < n_tiers; ++t) {
             const uint32_t PT_AS1* e = tt + 1 + PT_TIER_WORDS * t;

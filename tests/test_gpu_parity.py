@@ -312,6 +312,25 @@ def test_tier_schedule_bitwise(gpu, orc, cornell):
                 assert [t["cost_class"] for t in tiers] == sorted(t["cost_class"] for t in tiers)
             if whole == 0:
                 assert st["whole_pixels"] == 0 and not tiers
+        # tiny frames: fewer pixels than a wave has lanes, one pixel, a ragged size (always planned: <= 16 pixels per resident wave)
+        gpu.set_option("whole", -1)
+        S = orc.Scene(cornell["flat"])
+        for w, h in ((1, 1), (3, 2), (17, 5)):
+            cam_s = _cam(cornell, w, h)
+            got, _ = gpu.render(cam_s, w, h, 64, 16)
+            assert gpu.stats()["launches"] == 2 and gpu.read_tiers(), (w, h)
+            want_s, _, _ = S.render(_ocam(orc, cam_s), orc.make_env(**env), w, h, 64, 16)
+            assert_bitwise(got, want_s, "tiers, %dx%d" % (w, h))
+        # a frame that fills a good part of the chip, planned (forced) against the ring schedule: every pixel, every bit
+        # (workgroups beyond the plan once took tickets from the first tier's counter: its pixels stayed black now and then)
+        W2, H2 = 320, 200
+        cam2 = _cam(cornell, W2, H2)
+        imgs = {}
+        for whole in (1, 0):
+            gpu.set_option("whole", whole)
+            imgs[whole], _ = gpu.render(cam2, W2, H2, 48, 16)
+            assert (gpu.stats()["whole_pixels"] != 0) == (whole == 1)
+        assert_bitwise(imgs[1], imgs[0], "tiers vs ring, %dx%d" % (W2, H2))
     finally:
         gpu.set_option("whole", -1)
         gpu.set_option("count", 0)
