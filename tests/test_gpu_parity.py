@@ -331,6 +331,16 @@ def test_tier_schedule_bitwise(gpu, orc, cornell):
             imgs[whole], _ = gpu.render(cam2, W2, H2, 48, 16)
             assert (gpu.stats()["whole_pixels"] != 0) == (whole == 1)
         assert_bitwise(imgs[1], imgs[0], "tiers vs ring, %dx%d" % (W2, H2))
+        # more pixels than path slots, plan forced: the slots of a tier take one pixel after the other (rounds)
+        W3, H3 = 1280, 720
+        cam3 = _cam(cornell, W3, H3)
+        for whole in (1, 0):
+            gpu.set_option("whole", whole)
+            imgs[whole], _ = gpu.render(cam3, W3, H3, 32, 16)
+            if whole == 1:
+                t3 = gpu.read_tiers()
+                assert t3 and sum(t["waves"] * t["per_wave"] for t in t3) < W3 * H3
+        assert_bitwise(imgs[1], imgs[0], "tiers with rounds vs ring, %dx%d" % (W3, H3))
     finally:
         gpu.set_option("whole", -1)
         gpu.set_option("count", 0)
@@ -403,13 +413,16 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     # of the samples, no halving tail, a 1-sample pre-pass, no neighbourhood smoothing, few slots per wave
     S = orc.Scene(cornell["flat"])
     oenv = orc.make_env(color=(1, 1, 1), intensity=0.0)
-    for spp, opts in ((32, {}), (33, {"sticky_pct": 1}), (41, {"sticky_pct": 100}), (37, {"chunk_tail_min": 0, "sticky_pct": 50}),
-                      (36, {"prepass_spp": 1, "cost_radius": 0}), (45, {"prepass_spp": 11, "chunk_tail_min": 3, "slots_per_wave": 64})):
+    # (whole = 0: these are options of the ring schedule; a frame this small would otherwise get a tier plan - the last two cases)
+    for spp, opts in ((32, {"whole": 0}), (33, {"sticky_pct": 1, "whole": 0}), (41, {"sticky_pct": 100, "whole": 0}), (37, {"chunk_tail_min": 0, "sticky_pct": 50, "whole": 0}),
+                      (36, {"prepass_spp": 1, "cost_radius": 0, "whole": 0}), (45, {"prepass_spp": 11, "chunk_tail_min": 3, "slots_per_wave": 64, "whole": 0}),
+                      (32, {}), (71, {"prepass_spp": 3, "cost_radius": 0})):
         for k, v in opts.items():
             gpu.set_option(k, v)
         got, _ = gpu.render(cam, W, H, spp, 16)
         assert gpu.stats()["launches"] == 2, (spp, opts)
-        for k, v in {"sticky_pct": 75, "chunk_tail_min": -1, "prepass_spp": 0, "cost_radius": 2, "slots_per_wave": 0}.items():
+        assert (gpu.stats()["whole_pixels"] != 0) == ("whole" not in opts), (spp, opts)
+        for k, v in {"sticky_pct": -1, "chunk_tail_min": -1, "prepass_spp": 0, "cost_radius": 2, "slots_per_wave": 0, "whole": -1}.items():
             gpu.set_option(k, v)
         want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, spp, 16)
         assert_bitwise(got, want, "schedule %r at %d spp" % (opts, spp))
@@ -418,10 +431,16 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     for r in range(3):
         gpu.set_pixel_shard(r, 3, 16)
         part, _ = gpu.render(cam, W, H, 23, 16)
+        if r == 1:  # the same shard with the cost-ordered queue and its tier plan: identical
+            part70, _ = gpu.render(cam, W, H, 70, 16)
+            assert gpu.stats()["launches"] == 2 and gpu.stats()["whole_pixels"] != 0
         own = np.zeros(W * H, bool)
         own[B.shard_pixels(W, H, 16, r, 3)] = True
         own = own.reshape(H, W)[::-1]  # framebuffer rows are flipped (device.cu:251)
         assert not part[~own].any()
+        if r == 1:
+            assert not part70[~own].any()
+            assert_bitwise(part70[own], by_cost[own], "shard 1/3 with a tier plan == the full frame on its tiles")
         acc += part
     gpu.set_pixel_shard(0, 1, 16)
     assert_bitwise(acc, full, "sum of shards == full")
