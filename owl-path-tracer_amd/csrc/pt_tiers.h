@@ -95,5 +95,5 @@ PT_TIERS_FN void pt_plan_tiers(const uint32_t* start, int capacity, int ns, int 
         wave += w;
         ++n_tiers;
     }
-    tiers[0] = n_tiers;
+    tiers[0] = wave <= (uint32_t)capacity ? n_tiers : 0u; // (a plan that does not fit cannot happen from 64 resident waves on; if it does: ring schedule)
 }

@@ -250,6 +250,17 @@ def test_tier_plan_on_the_host():
     one[0] = 1
     tiers = B.plan_tiers(one, cap, ns)
     assert len(tiers) == 1 and tiers[0]["waves"] == 1 and tiers[0]["per_wave"] == 4
+    # whatever the histogram and the number of resident waves: the plan fits or declines
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        h = np.zeros(32, np.uint32)
+        k = int(rng.integers(1, 12))
+        h[rng.choice(32, k, replace=False)] = rng.integers(1, int(10 ** rng.uniform(0.5, 6.3)), k)
+        cap_i = int(rng.choice([1, 2, 7, 64, 256, 2048, 4096]))
+        ns_i = int(rng.choice([64, 96, 104]))
+        t = B.plan_tiers(h, cap_i, ns_i, force=bool(rng.integers(0, 2)))
+        if t:
+            _check_tiers(t, h, cap_i, ns_i)
     # bad arguments are refused
     t = np.zeros(257, np.uint32)
     assert B.lib().pt_debug_plan_tiers(one.ctypes.data_as(C.POINTER(C.c_uint32)), 0, 96, 0, t.ctypes.data_as(C.POINTER(C.c_uint32)), 257) < 0
