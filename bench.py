@@ -54,7 +54,7 @@ def algorithmic_bytes(st, n_pixels_out, textured_scatters=0):
     return st["nodes"] * 64 + st["tris"] * 36 + st["scatters"] * 152 + textured_scatters * 28 + st["env_misses"] * 4 + n_pixels_out * 12
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", "r%02d_traffic.json" % r) for r in range(9, 2, -1)]  # the newest committed PMC summary whose kernel fingerprint matches
 GOLDEN_CRC = os.path.join(ROOT, "tests", "golden", "c4_frame_crc.json")
 
 
@@ -69,22 +69,25 @@ def kernel_fingerprint():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(world):
-    """HBM/fabric bytes per launch of the render kernel from rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE in
-    separate passes; FETCH_SIZE x 1024 is the byte count for this kernel's 64-byte gathers: profiles/r01_fetch_calibration.md).
-    PMC cannot be collected from inside the timed run, so the figure is read from the committed summary of the profiling run
-    (tools/profile_round.sh writes it together with the fingerprint of the kernel sources); null when the kernel has changed
-    since, when the file is absent, or for N > 1."""
-    if world != 1 or not os.path.exists(TRAFFIC_JSON):
+def measured_pmc(world):
+    """PMC summary of the main launch from rocprofv3 passes of THIS command (FETCH_SIZE and WRITE_SIZE in separate passes;
+    FETCH_SIZE x 1024 is the byte count for this kernel's 64-byte gathers: profiles/r01_fetch_calibration.md).
+    PMC cannot be collected from inside the timed run, so the figures are read from the committed summary of the profiling run
+    (tools/profile_round.sh + tools/publish_profile.py write it together with the fingerprint of the kernel sources); None when the
+    kernel has changed since, when no file matches, or for N > 1."""
+    if world != 1:
         return None
-    try:
-        with open(TRAFFIC_JSON) as f:
-            d = json.load(f)
-        if d.get("kernel_fingerprint") != kernel_fingerprint():
-            return None
-        return int(d["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+    fp = kernel_fingerprint()
+    for path in TRAFFIC_JSONS:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("kernel_fingerprint") == fp:
+                d["file"] = os.path.relpath(path, ROOT)
+                return d
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def frame_crc(rgb):
@@ -253,6 +256,9 @@ def main():
         alg_bin = algorithmic_bytes(cst_bin, own_pixels) * main_share  # binary-visit equivalents of the same rays
         achieved_bin = alg_bin / (main_ms * 1e-3) / 1e9
         samples = W * H * SPP * args.steps
+        pmc = measured_pmc(world)
+        pmc_traffic = int(pmc["traffic_bytes_per_launch"]) if pmc else None
+        pmc_binding = pmc.get("binding") if pmc else None
         out = {
             "metric": "Msamples/sec at 1920x1080x1024spp",
             "value": round(samples / elapsed / 1e6, 2),
@@ -274,17 +280,26 @@ def main():
                        "tiles": "%dx%d round-robin over %d rank(s), one RCCL reduce of the float3 framebuffer inside the library (pt_comm_init_rank)" % (D.TILE, D.TILE, world),
                        "kernel": "wavefront-scheduled megakernel; per frame: cost pre-pass launch (%d spp) + queue sort + one persistent main launch" % (int(st.get("prepass_spp", 0)) or PREPASS_SPP), "triangles": int(st["n_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
                        "bvh_depth": int(st["bvh_depth"])},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(world),
-                         "accounting": "achieved = bytes of the records this build fetches (quad node 2 x 64 B, oct node 4 x 64 B per visit, 36 B per triangle test, "
-                                       "152 B per scatter, 12 B per pixel) / duration of the main launch; *_binary_equiv = the same rays counted as a plain BVH2 walk "
-                                       "of the same tree (64 B per node visit): a figure that cannot move by repacking records",
-                         "achieved_binary_equiv": round(achieved_bin, 1), "frac_binary_equiv": round(achieved_bin / HBM_PEAK_GBS, 4),
-                         "algorithmic_bytes_per_launch_binary_equiv": int(alg_bin),
+            # `achieved` = algorithmic bytes in ITS unit - 64 B per BVH2 node visit (the rays of this frame counted as a plain
+            # binary walk of the same tree by the instrumented instance), 36 B per triangle test, 152 B per scatter, 12 B per pixel - over
+            # the duration of the main launch.  These bytes are mostly served by the caches: `traffic` / `hbm_measured_*` is what the PMC
+            # counters saw beyond L2, and `binding` what the same profile says the kernel actually waits for.
+            "roofline": {"bound": "hbm", "achieved": round(achieved_bin, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_bin / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic,
+                         "hbm_measured_gbs": round(pmc_traffic / (main_ms * 1e-3) / 1e9, 1) if pmc_traffic else None,
+                         "hbm_measured_frac": round(pmc_traffic / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pmc_traffic else None,
+                         "binding": pmc_binding,
+                         "accounting": "achieved = SURVEY 8(d) algorithmic bytes (64 B per BVH2 node visit of the same rays on the same tree, counted by the "
+                                       "instrumented one-level walk; 36 B per triangle test; 152 B per scatter; 12 B per pixel) / duration of the main launch; "
+                                       "*_as_fetched = bytes of the records this build requests (quad node 2 x 64 B, oct node 4 x 64 B per visit): not an HBM figure "
+                                       "(can exceed the peak: the working set is cache resident); traffic = FETCH_SIZE + WRITE_SIZE of the main launch (rocprofv3 "
+                                       "PMC, separate passes, %s); hbm_measured_frac = traffic / main-launch time / peak"
+                                       % (pmc["file"] if pmc else "no committed PMC summary matches this kernel build"),
+                         "achieved_as_fetched": round(achieved, 1), "frac_as_fetched": round(achieved / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bin), "algorithmic_bytes_per_launch_as_fetched": int(alg_bytes),
                          "counts_per_frame_rank0_binary_walk": {k: int(cst_bin[k]) for k in ("rays", "nodes", "tris", "scatters")},
                          "kernel": "pt_render_wave_kernel<false>, main launch", "kernel_ms_per_launch": round(main_ms, 3), "launches_per_step": launches,
                          "prepass_and_sort_ms": round(p_ms, 3), "kernel_ms_per_frame": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_per_frame": int(alg_frame),
                          "counts_per_frame_rank0": {k: int(cst[k]) for k in ("samples", "rays", "nodes", "tris", "scatters", "env_misses")},
                          "vgprs": st["vgprs"], "lds_bytes": st["lds_bytes"], "grid": st["grid"], "block": st["block"]},
         }

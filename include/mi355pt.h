@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 #define PT_MAT_FLOATS 17 /* material_data: device_global.hpp:19-36, 68 bytes, field order kept */
 
 enum {
@@ -100,6 +100,10 @@ typedef struct pt_stats {
     int32_t express_pixels; /* pixels of the last cost-ordered launch that were rendered as express pixels (waves of their own) */
     int32_t whole_pixels;   /* other pixels of that launch that kept their path slot for all samples (whole-pixel schedule: every pixel had a slot from the start); 0: ring schedule */
     int32_t prepass_spp;    /* samples per pixel of the cost pre-pass launch of the last render (0: the render did not sort) */
+    /* counted renders, hit-shading passes by sampled lobe (disney.cuh:9-13: 0 diffuse, 1 clearcoat, 2 metallic, 3 glass; 4 = emitter hit,
+     * 5 = NaN retry): [0..5] items, [8..13] passes in which at least one item took that branch, [14] passes that ran two or more BSDF
+     * bodies, [15] passes whose items all took the same branch */
+    uint64_t lobes[16];
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
@@ -188,14 +192,15 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   "prepass_spp" (0 = automatic: 8, or 16 when a tier plan is prepared), "cost_radius" (2: the cost of a pixel - the time its pre-pass
  *   samples took - is de-noised by the mean over the look-alike pixels of its (2r+1)^2 neighbourhood), "whole" -1 (default: a launch
  *   whose pixels can all have a path slot from the start hands out whole pixels by cost class if a plan made on the device says so)
- *   | 0 (never: ring schedule) | 1 (always), "sticky_pct" (automatic, 10-75: share of the
+ *   | 0 (never: ring schedule) | 1 (always), "sticky_pct" (automatic: min(80, 50 + 6 x pixels per path slot) %: share of the
  *   remaining samples a pixel gets in its first chunk), "chunk_spp" (64, schedule 0), "chunk_tail_min" (-1 = automatic: an eighth of the
  *   samples after the pre-pass, at least 16: smallest of the halving tail chunks; 0 = no tail), "spp_per_launch" (kernel 1: samples per launch; kernel 2: forces schedule 0 with this
  *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build;
  *   "groups" 1 (default: a wave with few rays to trace walks them eight lanes per ray over oct nodes) | 0 (never) | 2 (always: tests),
  *   "wide_leaves" 1 (oct nodes: subtrees of <= 7 triangles are one leaf step; next pt_upload_scene), "tune6" / "tune7" (16 / 24: ray-queue
- *   level and running pixels up to which a wave counts as sparse);  "coop" 0 (default) | 1: the quad nodes of all lanes are fetched
- *   cooperatively as whole cache lines through an LDS staging area (2x the node-fetch rate, but 8 KB of LDS per wave: 9 waves per CU);
+ *   level and running pixels up to which a wave counts as sparse);  "coop" / "quant": two validated experiments that are NOT in the product
+ *   build (cooperative whole-line node fetch through an LDS staging area; 64-byte quad nodes with 8-bit planes) - builds made with
+ *   EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1" contain them (default on there); elsewhere setting either to 1 returns PT_E_INVALID;
  *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
  *   the library does by itself when the 128-VGPR instance of a build needs scratch). */
 int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);

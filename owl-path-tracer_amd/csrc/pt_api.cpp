@@ -10,28 +10,8 @@
 #include <vector>
 
 #include "pt_internal.h"
+#include "pt_launch.h"
 #include "pt_tiers.h"
-
-extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelParams* d_params, int variant, int grid, size_t lds_bytes,
-                                       hipStream_t stream, int count);
-extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const float* in, int in_stride, float* out, int out_stride, long long n,
-                                      size_t lds_bytes, hipStream_t stream);
-extern "C" size_t pt_sort_scratch_bytes(uint32_t n);
-extern "C" hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream);
-extern "C" hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0,
-                                            uint32_t* scratch, uint8_t* bucket, hipStream_t stream);
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
-                                         size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
-extern "C" int pt_debug_block(void);
-extern "C" int pt_kernel_features(void);
-extern "C" hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream);
-extern "C" size_t pt_lbvh_workspace_bytes(int n);
-extern "C" hipError_t pt_lbvh_build_device(const float* d_pos, int n, int leaf_size, void* d_workspace, size_t workspace_bytes, PtNode* d_nodes, uint32_t* d_order,
-                                           int32_t* h_root, int32_t* h_n_nodes, int32_t* h_height, int32_t* h_max_leaf, float* h_pad, hipStream_t stream);
-
-extern "C" size_t pt_ploc_workspace_bytes(int n);
-extern "C" hipError_t pt_ploc_build_device(const float* d_pos, int n, int radius, void* d_workspace, size_t workspace_bytes, int* h_child, float* h_box, int* h_count,
-                                           uint32_t* h_order, int32_t* h_root, int32_t* h_rounds, hipStream_t stream);
 
 #define PT_AUTO_PLOC_TRIS 2000000
 
@@ -299,9 +279,15 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "whole") c->whole = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // whole-pixel schedule by cost class when every pixel can have a path slot: -1 the plan decides (default), 0 never, 1 always
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
-    else if (k == "coop") c->coop = value != 0; // wavefront kernel + quad nodes: cooperative node fetch through LDS (default on)
+    else if (k == "coop") { // wavefront kernel + quad nodes: cooperative node fetch through LDS - only in builds made with -DPT_WITH_COOP=1 (default on there)
+        if (value && !(pt_kernel_features() & 1)) return fail(c, PT_E_INVALID, "option 'coop': this build has no cooperative node fetch (make EXTRA=-DPT_WITH_COOP=1)");
+        c->coop = value != 0;
+    }
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
-    else if (k == "quant") c->quant = value != 0; // wavefront kernel: 64-byte quad nodes on a 16-bit grid (default on)
+    else if (k == "quant") { // wavefront kernel: 64-byte quad nodes with 8-bit planes - only in builds made with -DPT_WITH_QUANT=1 (default on there)
+        if (value && !(pt_kernel_features() & 2)) return fail(c, PT_E_INVALID, "option 'quant': this build has no quantised quad nodes (make EXTRA=-DPT_WITH_QUANT=1)");
+        c->quant = value != 0;
+    }
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -610,6 +596,28 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
     int rc = ensure_queue(c, W, H);
     if (rc) return rc;
+    if (c->n_pixels == 0) {
+        // A rank that owns no tile (fewer tiles than ranks, e.g. 64x64 / tile 16 at world 8): its frame is all zeros and no kernel
+        // runs.  (Round-3 advisor finding: the main launch of such a rank read a tier table nobody had written - the sort and the
+        // plan kernel return early for an empty queue.)
+        HIP_TRY(c, hipEventRecord(c->ev0, stream));
+        HIP_TRY(c, hipMemsetAsync(d_out_rgb, 0, (size_t)W * H * 3 * sizeof(float), stream));
+        if (d_out_rgba8) HIP_TRY(c, hipMemsetAsync(d_out_rgba8, 0, (size_t)W * H * 4, stream));
+        HIP_TRY(c, hipEventRecord(c->ev1, stream));
+        c->ev_pending = true;
+        c->flag_pending = false;
+        c->last_stream = stream;
+        c->last_launches = 0;
+        c->last_sorted = false;
+        c->last_w = W;
+        c->last_h = H;
+        c->stats.express_pixels = 0;
+        c->stats.whole_pixels = 0;
+        c->stats.prepass_spp = 0;
+        c->stats.grid = 0;
+        if (c->count && c->d_counters.p) HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(PtCounters), stream));
+        return PT_OK;
+    }
 
     // kernel 1 (lane-per-pixel): optional spp chunks = separate launches.  kernel 2 (wavefront): ONE persistent launch that
     // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
@@ -990,6 +998,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
             c->stats.scatters = h.scatters; c->stats.env_misses = h.env_misses; c->stats.nan_retries = h.nan_retries;
             for (int i = 0; i < 32; ++i) c->stats.sched[i] = h.sched[i];
             for (int i = 0; i < 8; ++i) c->stats.groups[i] = h.grp[i];
+            for (int i = 0; i < 16; ++i) c->stats.lobes[i] = h.lobes[i];
         }
     }
     *out = c->stats;

@@ -19,6 +19,7 @@
 #include <mutex>
 
 #include "pt_internal.h"
+#include "pt_launch.h"
 
 namespace {
 
@@ -93,8 +94,6 @@ struct pt_group {
     uint32_t* pinned_rgba8 = nullptr;
     std::string err;
 };
-
-extern "C" hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long long n, hipStream_t stream);
 
 extern "C" {
 

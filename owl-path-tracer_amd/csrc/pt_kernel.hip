@@ -30,6 +30,7 @@
 
 #include "pt_device.h"
 #include "pt_tiers.h"
+#include "pt_launch.h"
 #include "pt_types.h"
 
 using namespace ptd;
@@ -91,6 +92,7 @@ struct Counters {
     uint32_t depth[4] = {};  // per lane: pushes, pushes at stack depth >= 8 / 12 / 16
     uint32_t grp[6] = {};    // wave-uniform census of the group walk: phases, iterations, busy groups, node groups, leaf groups, rays
     unsigned long long grp_cyc = 0;
+    uint32_t lobe[16] = {};  // wave-uniform census of the hit passes by sampled lobe (PtCounters::lobes)
 };
 
 // Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
@@ -583,6 +585,10 @@ __device__ __forceinline__ bool fetch_pixel(const PtKernelParams& P, uint32_t& p
 //     so "every storing wave" is this wave), and only then stores the flag - the ring cell - again sc1;
 //   * the consumer learns of it by an sc1 load poll of THAT cell, and the polling lane issues its loads of the bytes only after
 //     its poll has matched (start_chunk returns before them otherwise: a control dependency in the same lane).
+// The guide measured that row at ONE workgroup per CU; this kernel runs 16 one-wave workgroups per CU.  That it holds here as well is
+// an empirical statement: tests/test_gpu_parity.py::test_c4_dragon_standin_full_size hands every sample of every pixel of C4 on (64
+// one-sample chunks per pixel: 1.3e8 hand-offs in one launch) and compares the frame bit for bit with the one-chunk frame, and
+// bench.py asserts the crc of every timed frame (~4 M hand-offs each).
 // An agent-scope acquire per poll would also be correct but is 2-3x slower per hop and, with hundreds of pollers, costs the
 // whole chip bandwidth (same section, "Invalid forms"); a release would write back the XCD's L2.  Counters that are updated with
 // device-scope atomics (ticket heads, ring fills, the diagnostics accumulators) sit on cache lines that nothing stores to
@@ -744,6 +750,8 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
 #pragma unroll
         for (int k = 0; k < 6; ++k) atomicAdd(&P.counters->grp[k], (unsigned long long)cn.grp[k]);
         atomicAdd(&P.counters->grp[6], cn.grp_cyc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(&P.counters->lobes[k], (unsigned long long)cn.lobe[k]);
     }
     for (int k = 0; k < 4; ++k) {
         unsigned long long x = cn.depth[k];
@@ -955,6 +963,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
     int ps_slot = 0;
     bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
+    int branch = -1; // COUNT: which branch of the hit shader the item took (0..3 sampled lobe, 4 emitter, 5 NaN retry)
     if (mine) {
         ps_slot = (int)q[w.wrap(q_head + lane)];
         uint32_t pid = GF(S_PIX, ps_slot);
@@ -985,7 +994,9 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             if (P.dbg_start && !P.cost_out) atomicAdd(P.dbg_start + (size_t)P.width * (size_t)P.height + (uint32_t)px + (uint32_t)P.width * (uint32_t)py, 1u); // diagnostics: rays per pixel
             v3 radiance;
             const int tslot = IS_MISS ? -1 : (int)LF(L_AZ, ps_slot);
+            const uint32_t scat0 = cn.scat;
             int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
+            if (COUNT && !IS_MISS) branch = r == SR_RETRY ? 5 : (cn.scat != scat0 ? ps.lobe : 4);
             if (r == SR_RETRY) {
                 to_hit = true; // same hit, fresh draws (device.cu:196-201); L_A* still hold the hit
             } else if (r == SR_END) {
@@ -1051,6 +1062,19 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 }
             }
         }
+    }
+    if (COUNT && !IS_MISS) {
+        int bodies = 0, branches = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const unsigned long long mb = __ballot(branch == b);
+            cn.lobe[b] += (uint32_t)popc64(mb);
+            cn.lobe[8 + b] += mb != 0ull;
+            bodies += (b < 4 && mb != 0ull) ? 1 : 0;
+            branches += mb != 0ull ? 1 : 0;
+        }
+        cn.lobe[14] += bodies >= 2;
+        cn.lobe[15] += branches == 1;
     }
     q_head = w.wrap(q_head + n);
     q_count -= n;

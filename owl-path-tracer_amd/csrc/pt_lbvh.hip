@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "pt_launch.h"
 #include "pt_types.h"
 
 namespace {

@@ -5,13 +5,13 @@
 // reaches these functions (every render path refuses first: "no CPU fallback").  Not part of libmi355pt.so.
 #include <hip/hip_runtime.h>
 
-#include "pt_types.h"
+#include "pt_launch.h"
 
 extern "C" {
 hipError_t pt_launch_render(const PtKernelParams*, const PtKernelParams*, int, int, size_t, hipStream_t, int) { return hipErrorNotSupported; }
 hipError_t pt_launch_debug(const PtKernelParams*, int, const float*, int, float*, int, long long, size_t, hipStream_t) { return hipErrorNotSupported; }
 size_t pt_sort_scratch_bytes(uint32_t) { return 16; }
-hipError_t pt_launch_plan_tiers(const uint32_t*, uint32_t, int, int, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t pt_launch_plan_tiers(const uint32_t*, uint32_t, int, int, int, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_sort_pixels(const uint8_t*, int, int, int, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_kernel_geometry(int, int, int, int, int, int, int*, size_t*, int*, size_t*, int*, int*, int*) { return hipErrorNotSupported; }
 int pt_debug_block(void) { return 256; }

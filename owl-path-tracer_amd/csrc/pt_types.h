@@ -107,6 +107,10 @@ struct PtCounters {
     unsigned long long sched[32];
     // group walk (sparse waves): {phases, iterations, sum of busy groups, sum of node groups, sum of leaf groups, rays traced, shader-clock cycles, unused}
     unsigned long long grp[8];
+    // hit passes by sampled lobe (disney.cuh:9-13 order: 0 diffuse, 1 clearcoat, 2 metallic, 3 glass; 4 = emitter hit, 5 = NaN retry):
+    // [0..5] items, [8..13] hit passes in which at least one item took that branch (executions of that body), [14] passes with two or
+    // more BSDF bodies, [15] passes whose items all took one branch
+    unsigned long long lobes[16];
 };
 
 #define PT_MAX_TAIL_CHUNKS 20

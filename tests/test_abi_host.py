@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "missing export " + n
     assert sorted(B.EXPORTS) == names
-    assert B.lib().pt_abi_version() == 4
+    assert B.lib().pt_abi_version() == 5
 
 
 def test_create_without_gpu_fails_loudly_or_succeeds_on_gfx950():

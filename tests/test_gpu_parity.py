@@ -268,7 +268,7 @@ def test_cost_ordered_queue_properties(gpu, cornell):
     own = B.shard_pixels(W, H, 16, 1, 2)
     np.testing.assert_array_equal(ids, own)
     np.testing.assert_array_equal(np.sort(q), np.sort(own))
-    assert cost.min() >= 1 and cost.max() > cost.min()  # a class per pixel of the shard (0 = not this rank's), and not all the same
+    assert cost.min() >= 1  # a class per pixel of the shard (0 = not this rank's); the classes are wall-clock times: nothing else about their values is asserted
     cls = _queue_classes(ids, cost, q, W, H)
     assert np.all(np.diff(cls) >= 0), "queue buckets must be non-decreasing (bucket 0 = most expensive first)"
     # stable within a class: input order is kept
@@ -466,6 +466,38 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
     assert_bitwise(swept, want, "after pt_set_materials")
 
 
+def test_empty_rank_and_world8_sum(gpu, cornell):
+    """A rank that owns no tile (64x64 / tile 16 has 16 tiles on 7 diagonals: rank 7 of 8 gets none) renders a zero frame without
+    launching a kernel - at 40 spp the cost-ordered schedule with a tier plan would otherwise read a table nobody wrote (round-3
+    advisor finding) - and the eight shards still sum to the full frame."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    W = H = 64
+    cam = _cam(cornell, W, H)
+    full, full8 = gpu.render(cam, W, H, 40, 16, want_rgba8=True)
+    assert B.shard_pixels(W, H, 16, 7, 8).size == 0
+    acc = np.zeros_like(full)
+    acc8 = np.zeros_like(full8)
+    try:
+        for r in range(8):
+            gpu.set_pixel_shard(r, 8, 16)
+            part, part8 = gpu.render(cam, W, H, 40, 16, want_rgba8=True)
+            st = gpu.stats()
+            if r == 7:
+                assert not part.any() and not part8.any() and st["launches"] == 0
+                gpu.set_option("count", 1)  # the counted instance takes the same early exit
+                part, _ = gpu.render(cam, W, H, 40, 16)
+                gpu.set_option("count", 0)
+                assert not part.any()
+            else:
+                assert st["launches"] == 2
+            acc += part
+            acc8 += part8  # disjoint pixels: 0 where not owned
+    finally:
+        gpu.set_pixel_shard(0, 1, 16)
+    assert_bitwise(acc, full, "sum of 8 shards (one of them empty) == full")
+    np.testing.assert_array_equal(acc8, full8)
+
+
 def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
     """option kernel=1 (persistent lane-per-pixel scheduler) must produce the same bits as the default wavefront scheduler."""
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
@@ -562,6 +594,23 @@ def test_c4_dragon_standin_full_size(gpu, orc, scene_io, procedural):
     assert zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF == want_crc, "C4 frame differs from tests/golden/c4_frame_crc.json (re-run bench.py --write-golden after an intended change)"
     _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C4")    # single launch, queue order
     _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 32, 16, "C4")   # cost pre-pass + sorted queue + rings
+    # hand-off stress (round-3 verdict item 5): every sample of every pixel a work item of its own - 64 chunks per pixel, 1.3e8
+    # cross-wave hand-offs of (rng, accum) through the rings at 16 one-wave workgroups per CU (pt_kernel.hip, finish_chunk /
+    # start_chunk) - against the frame whose pixels never change hands (one chunk).  A difference is a lost or stale publication.
+    for k, v in (("schedule", 0), ("chunk_spp", 64)):
+        gpu.set_option(k, v)
+    try:
+        whole64, _ = gpu.render(cam, W, H, 64, 16)
+        assert gpu.stats()["launches"] == 1
+        gpu.set_option("chunk_spp", 1)
+        gpu.set_option("chunk_tail_min", 0)
+        handed, _ = gpu.render(cam, W, H, 64, 16)
+        ho_ms = gpu.stats()["kernel_ms"]
+    finally:
+        for k, v in (("schedule", 1), ("chunk_spp", 64), ("chunk_tail_min", -1)):
+            gpu.set_option(k, v)
+    assert_bitwise(handed, whole64, "C4 64 spp: 64 one-sample chunks per pixel == one chunk per pixel")
+    print("C4 hand-off stress: %d hand-offs in %.0f ms" % (W * H * 63, ho_ms))
     # shards: rank 3 of 8 renders only its tiles, and exactly the full image's values there
     gpu.set_pixel_shard(3, 8, 16)
     part, _ = gpu.render(cam, W, H, 1024, 16)

@@ -9,7 +9,45 @@ ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
 
 PRE_UPLOAD = ("leaf_size", "max_bvh_depth", "node_pairs", "leaf_align", "bvh_builder", "ploc_radius", "wide_leaves")  # builder / layout options: before upload_scene
-NOT_OPTIONS = ("finish", "tiers", "spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain")
+NOT_OPTIONS = ("finish", "tiers", "spp", "census", "shard_rank", "shard_world", "shard_tile", "detail_u", "detail_v", "chain", "sweep", "frame_out")
+
+# C3 material sweep ("for BSDF coverage add a material sweep over metallic/clearcoat/transmission/sheen"; the reference's
+# driver is test_loop / modify_sbt, application.hpp:89-108, application.cpp:329-360): the attribute is set on the two objects of the
+# mitsuba stand-in ('outside', 'inside'; 'ground' stays diffuse) through pt_set_materials, one frame per value - the per-lobe cost harness.
+SWEEP = [("base", {}), ("metallic=1,roughness=0.3", {4: 1.0, 7: 0.3}), ("metallic=0.5", {4: 0.5}), ("clearcoat=1", {11: 1.0}),
+         ("specular_transmission=1", {14: 1.0}), ("specular_transmission=0.5,tr_roughness=0.3", {14: 0.5, 15: 0.3}), ("sheen=1", {9: 1.0}),
+         ("all four lobes: metallic .3, clearcoat 1, transmission .5, sheen .5", {4: 0.3, 11: 1.0, 14: 0.5, 9: 0.5})]
+LOBE_NAMES = ["diffuse", "clearcoat", "metallic", "glass", "emitter", "nan_retry"]
+
+
+def lobe_census(cs):
+    lb = cs["lobes"]
+    tot = max(1, sum(lb[:6]))
+    out = {"items": {n: lb[i] for i, n in enumerate(LOBE_NAMES)}, "share": {n: round(lb[i] / tot, 4) for i, n in enumerate(LOBE_NAMES)},
+           "lanes_per_body_execution": {n: round(lb[i] / max(1, lb[8 + i]), 2) for i, n in enumerate(LOBE_NAMES) if lb[i]},
+           "hit_passes": cs["sched"][6], "bodies_per_pass": round(sum(lb[8:12]) / max(1, cs["sched"][6]), 3),
+           "passes_with_2+_bodies": round(lb[14] / max(1, cs["sched"][6]), 4), "passes_single_branch": round(lb[15] / max(1, cs["sched"][6]), 4)}
+    return out
+
+
+def cached_meshes(name, make):
+    """The procedural stand-ins take up to 18 s to generate in numpy: keep them in /tmp for the later invocations of the same GPU-box session."""
+    path = "/tmp/ptamd_mesh_%s.npz" % name
+    if os.path.exists(path):
+        z = np.load(path, allow_pickle=False)
+        names = [str(x) for x in z["names"]]
+        return [(n, dict(vertices=z["v%d" % i], normals=z["n%d" % i], texcoords=z["t%d" % i], indices=z["i%d" % i])) for i, n in enumerate(names)]
+    ms = make()
+    d = {"names": np.array([n for n, _ in ms])}
+    for i, (_, m) in enumerate(ms):
+        d["v%d" % i] = m["vertices"]; d["n%d" % i] = m["normals"]; d["i%d" % i] = m["indices"]
+        d["t%d" % i] = m["texcoords"]
+    try:
+        np.savez(path + ".tmp.npz", **d)
+        os.replace(path + ".tmp.npz", path)
+    except OSError:
+        pass
+    return ms
 
 
 def main():
@@ -23,7 +61,7 @@ def main():
     if which == "c4":
         _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "dragon.json"))
         du = int(opts.get("detail_u", 4357)); dv = int(opts.get("detail_v", 100))
-        ents = scene_io.build_entities(procedural.dragon_standin(du, dv), mats)
+        ents = scene_io.build_entities(cached_meshes("dragon_%d_%d" % (du, dv), lambda: procedural.dragon_standin(du, dv)), mats)
         W, H, spp = 1920, 1080, int(opts.get("spp", 1024))
         cam = B.to_camera_data([4, 2.5, 0], [0, .75, 0], [0, 1, 0], 50, W, H)
     elif which == "c3":
@@ -33,7 +71,7 @@ def main():
         cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
     elif which == "c5":
         _, mats = scene_io.parse_scene(os.path.join(ROOT, "assets", "car.json"))
-        ents = scene_io.build_entities(procedural.car_standin(), mats)
+        ents = scene_io.build_entities(cached_meshes("car", procedural.car_standin), mats)
         W, H, spp = 1920, 1080, int(opts.get("spp", 4096))
         cam = B.to_camera_data([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, W, H)
     else:
@@ -56,11 +94,38 @@ def main():
     for k, v in opts.items():
         if k not in PRE_UPLOAD and k not in NOT_OPTIONS:
             ctx.set_option(k, int(v))
+    if opts.get("sweep"):  # c3 sweep=1: one timed frame (+ one counted frame) per material variant
+        base = np.stack([m for _, m, _ in mats]).astype(np.float32)
+        names = [n for n, _, _ in mats]
+        for label, edits in SWEEP:
+            mm = base.copy()
+            for i, n in enumerate(names):
+                if n != "ground":
+                    for k, v in edits.items():
+                        mm[i, k] = v
+            ctx.set_materials(mm)
+            t = []
+            for _ in range(reps):
+                ctx.render(cam, W, H, spp, 16)
+                t.append(ctx.stats()["kernel_ms"])
+            ctx.set_option("count", 1)
+            ctx.render(cam, W, H, spp, 16)
+            cs = ctx.stats()
+            ctx.set_option("count", 0)
+            cyc = dict(zip(["node", "tri", "retire", "hit_pass", "miss_pass", "park_resume", "sleep", "total"], cs["sched"][24:32]))
+            print(json.dumps({"sweep": label, "kernel_ms_min": round(min(t), 2), "Msamples/s": round(W * H * spp / min(t) / 1e3, 1), "rays_per_sample": round(cs["rays"] / max(1, cs["samples"]), 3),
+                              "nodes_per_ray": round(cs["nodes"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris"] / max(1, cs["rays"]), 2), "nan_retries": cs["nan_retries"],
+                              "cycle_share": {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}, "hit_items/pass": round(cs["sched"][7] / max(1, cs["sched"][6]), 2),
+                              "lobes": lobe_census(cs)}))
+        return
     ms = []
     for _ in range(reps):
-        ctx.render(cam, W, H, spp, 16)
+        rgb, _ = ctx.render(cam, W, H, spp, 16)
         ms.append(ctx.stats()["kernel_ms"])
     st = ctx.stats()
+    if opts.get("frame_out"):  # crc of the float frame: A/B runs must agree bit for bit
+        import zlib
+        print(json.dumps({"frame_crc32": "%08x" % (zlib.crc32(np.ascontiguousarray(rgb, np.float32).tobytes()) & 0xFFFFFFFF)}))
     if opts.get("tiers"):
         print(json.dumps({"tiers(pixels,per_wave,waves,class)": [(t["pixels"], t["per_wave"], t["waves"], t["cost_class"]) for t in ctx.read_tiers()]}))
     if opts.get("finish"):
@@ -126,6 +191,11 @@ def main():
         cen["winddown_ray_share"] = round(cen["rays_after_death"] / max(1, cen["rays"]), 4)
         cen["winddown_time_share"] = round(cen["winddown_ticks"] / max(1, cyc["total"]), 4)
         cen["cycle_share"] = {k: round(v / max(1, cyc["total"]), 4) for k, v in cyc.items()}
+        cen["nodes_per_ray"] = round(cs["nodes"] / max(1, cs["rays"]), 2)
+        cen["tris_per_ray"] = round(cs["tris"] / max(1, cs["rays"]), 2)
+        cen["rays_per_sample"] = round(cs["rays"] / max(1, cs["samples"]), 3)
+        cen["env_misses"] = cs["env_misses"]
+        cen["lobes"] = lobe_census(cs)
         g = cs["groups"]
         cen["groups"] = {"phases": g[0], "iters": g[1], "iters/phase": round(g[1] / max(1, g[0]), 2), "busy_groups/iter": round(g[2] / max(1, g[1]), 2),
                          "node_groups/iter": round(g[3] / max(1, g[1]), 2), "leaf_groups/iter": round(g[4] / max(1, g[1]), 2), "rays": g[5],

@@ -41,5 +41,20 @@ traffic = {
     "traffic_bytes_per_launch": int(d["fetch_bytes"] + d["write_bytes"]), "l2_hit_rate": d["l2_hit_rate"],
     "kernel_ms": sum(pmc["main_launch_ms"]) / len(pmc["main_launch_ms"]),
 }
+# What binds (round-3 verdict item 2): the PMC ceilings of the same main launch, in units a reader can compare with 1.0.
+# SQ_* busy/wait counters are quad-cycles summed over waves (MI355X_MICROARCH.md, constants table); GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+cn = pmc["counters_per_main_launch"]
+if all(k in cn for k in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")):
+    cyc = cn["GRBM_GUI_ACTIVE"] / 8.0  # shader-clock cycles of the launch
+    cus, simds = 256, 1024
+    traffic["binding"] = {
+        "valu_busy": round(cn["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cyc), 3),        # share of SIMD cycles with a VALU instruction executing
+        "valu_lane_utilisation": round(d["valu_lane_utilization"], 3),                  # active lanes per VALU instruction / 64
+        "vl1d_accesses_per_cycle_per_cu": round(cn["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cus * cyc), 3),  # ceiling ~1 for per-lane gathers (profiles/r03_node_fetch.md)
+        "sq_wait_any_share": round(cn["SQ_WAIT_ANY"] / cn["SQ_WAVE_CYCLES"], 3),        # share of wave cycles spent waiting (s_waitcnt etc.)
+        "l2_hit_rate": round(d["l2_hit_rate"], 3),
+        "clock_ghz": round(cyc / (traffic["kernel_ms"] * 1e-3) / 1e9, 3),
+        "reading": "bound by VALU issue at partial lane utilisation together with the vector L1's per-lane gather rate; HBM is far from its peak",
+    }
 json.dump(traffic, open(os.path.join(dst, "r%02d_traffic.json" % rnd), "w"), indent=1)
 print(json.dumps({"value": bench["value"], "ms_per_step": bench["ms_per_step"], "roofline": bench["roofline"]["achieved"], "traffic": traffic["traffic_bytes_per_launch"]}))
