@@ -101,8 +101,8 @@ typedef struct pt_stats {
     int32_t whole_pixels;   /* other pixels of that launch that kept their path slot for all samples (whole-pixel schedule: every pixel had a slot from the start); 0: ring schedule */
     int32_t prepass_spp;    /* samples per pixel of the cost pre-pass launch of the last render (0: the render did not sort) */
     /* counted renders, hit-shading passes by sampled lobe (disney.cuh:9-13: 0 diffuse, 1 clearcoat, 2 metallic, 3 glass; 4 = emitter hit,
-     * 5 = NaN retry): [0..5] items, [8..13] passes in which at least one item took that branch, [14] passes that ran two or more BSDF
-     * bodies, [15] passes whose items all took the same branch */
+     * 5 = NaN retry): [0..5] items, [7] passes that shaded one lobe bin alone (option "lobe_bins"), [8..13] passes in which at least one
+     * item took that branch, [14] passes that ran two or more BSDF bodies, [15] passes whose items all took the same branch */
     uint64_t lobes[16];
 } pt_stats;
 
@@ -201,7 +201,9 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   level and running pixels up to which a wave counts as sparse);  "coop" / "quant": two validated experiments that are NOT in the product
  *   build (cooperative whole-line node fetch through an LDS staging area; 64-byte quad nodes with 8-bit planes) - builds made with
  *   EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1" contain them (default on there); elsewhere setting either to 1 returns PT_E_INVALID;
- *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
+ *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" -1 (default: when the scene's materials can sample two or more
+ *   different lobes, a hit pass shades the hits of ONE predicted lobe at a time) | 0 (never) | 1 (whenever the scene allows: < 2^23 triangles,
+ *   < 32 materials), "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
  *   the library does by itself when the 128-VGPR instance of a build needs scratch). */
 int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);

@@ -86,9 +86,43 @@ int upload_env(pt_ctx* c)
     return PT_OK;
 }
 
+// Lobe thresholds of one material for the lobe bins of the hit pass (pt_kernel.hip, LOBE-COHERENT HIT PASSES): the cumulative
+// selection probabilities of sample_disney in ITS order (disney.cuh:15-29,44-63: metallic, clearcoat, diffuse; glass is what is left)
+// in units of 1/512 of the draw, 10 bits each; bit 30: emitter (device.cu:157-161 ends the path before any lobe runs), bit 31: the
+// material has a glass lobe (force_btdf, disney.cuh:39).  A prediction aid only - the shader decides from the exact values.
+uint32_t pt_lobe_code(const float* m)
+{
+    const float metallic = m[4], clearcoat = m[11], transmission = m[14], emission = m[16];
+    const float wd = (1.0f - transmission) * (1.0f - metallic), wm = metallic, wc = 0.25f * clearcoat, wg = (1.0f - metallic) * transmission;
+    const float sum = wm + wg + wd + wc;
+    auto q = [&](float x) {
+        const float v = sum > 0.0f ? x / sum * 512.0f + 0.5f : 0.0f;
+        return (uint32_t)(v != v || v < 0.0f ? 0.0f : (v > 512.0f ? 512.0f : v));
+    };
+    const uint32_t t0 = q(wm), t1 = std::max(t0, q(wm + wc)), t2 = std::max(t1, q(wm + wc + wd));
+    return t0 | (t1 << 10) | (t2 << 20) | (emission > 0.0f ? 0x40000000u : 0u) | (wg > 0.0f ? 0x80000000u : 0u);
+}
+
 int upload_materials(pt_ctx* c)
 {
+    // the lobe-code table (index = material + 1; 0 = material_data{} defaults, device.cu:150-154) and whether the scene can sample
+    // more than one lobe at all (one lobe: the bins would only cost)
+    c->lobe_mask = 0;
+    std::memset(c->lobe_codes, 0, sizeof(c->lobe_codes));
+    const bool fits = c->n_materials + 1 <= PT_LOBE_TABLE;
+    static const float def_mat[PT_MAT_FLOATS] = {0.8f, 0.8f, 0.8f, 0.0f, 0.0f, 0.5f, 1.0f, 0.5f, 0.0f, 0.0f, 1.0f, 0.0f, 0.03f, 1.45f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; fits && i <= c->n_materials; ++i) {
+        const uint32_t code = pt_lobe_code(i == 0 ? def_mat : &c->materials[(size_t)(i - 1) * PT_MAT_STRIDE]);
+        c->lobe_codes[i] = code;
+        if (i == 0 && !c->uses_default_material) continue;
+        if (code & 0x40000000u) continue; // emitter: no lobe
+        const uint32_t t0 = code & 0x3ffu, t1 = (code >> 10) & 0x3ffu, t2 = (code >> 20) & 0x3ffu;
+        c->lobe_mask |= (t0 > 0 ? 4u : 0u) | (t1 > t0 ? 2u : 0u) | (t2 > t1 ? 1u : 0u) | (t2 < 512u ? 8u : 0u);
+    }
+    if (!fits) c->lobe_mask = 0;
     if (c->host_only) return PT_OK;
+    int rc = upload(c, c->d_lobe, c->lobe_codes, sizeof(c->lobe_codes));
+    if (rc) return rc;
     return upload(c, c->d_materials, c->materials.data(), c->materials.size() * sizeof(float));
 }
 
@@ -165,6 +199,11 @@ void fill_params(pt_ctx* c, PtKernelParams& P)
     P.n_materials = c->n_materials;
     P.stack_entries = c->bvh.depth < 1 ? 1 : c->bvh.depth;
     for (int i = 0; i < 8; ++i) P.tune[i] = c->tune[i];
+    P.lobe_codes = (const uint32_t*)c->d_lobe.p;
+    P.hit_slot_mask = c->tri_packed ? 0x00ffffffu : 0xffffffffu;
+    // lobe bins (wavefront kernel): automatic = when the materials of the scene can sample two or more different lobes
+    const int n_lobes = __builtin_popcount(c->lobe_mask);
+    P.lobe_bins = (c->kernel == 2 && c->tri_packed && c->lobe_mask != 0 && (c->lobe_bins > 0 || (c->lobe_bins < 0 && n_lobes >= 2))) ? 1 : 0;
 }
 
 } // namespace
@@ -236,7 +275,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
         DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4q, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
-                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket, &c->d_tiers};
+                          &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket, &c->d_tiers, &c->d_lobe};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -288,6 +327,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value && !(pt_kernel_features() & 2)) return fail(c, PT_E_INVALID, "option 'quant': this build has no quantised quad nodes (make EXTRA=-DPT_WITH_QUANT=1)");
         c->quant = value != 0;
     }
+    else if (k == "lobe_bins") c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // hit passes by predicted lobe: -1 automatic (default), 0 never, 1 whenever possible
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -330,8 +370,10 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     if (material_texture)
         for (int i = 0; i < n_materials; ++i) c->material_texture[i] = material_texture[i];
     size_t g = 0;
+    c->uses_default_material = false;
     for (int m = 0; m < n_meshes; ++m) {
         const pt_mesh& ms = meshes[m];
+        if (ms.material_index < 0 && ms.n_triangles > 0) c->uses_default_material = true;
         if (ms.n_triangles > 0 && (!ms.vertices || !ms.indices)) return fail(c, PT_E_INVALID, "mesh %d: null vertices/indices", m);
         if (ms.material_index >= n_materials) return fail(c, PT_E_INVALID, "mesh %d: material index %d out of range", m, ms.material_index);
         if (ms.texture_index >= n_textures) return fail(c, PT_E_INVALID, "mesh %d: texture index %d out of range", m, ms.texture_index);
@@ -484,7 +526,17 @@ int upload_scene_to_device(pt_ctx* c)
     if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
     if ((rc = upload(c, c->d_nodes8, c->nodes8.data(), c->nodes8.size() * sizeof(PtNode8)))) return rc;
     if ((rc = upload(c, c->d_nodes4q, c->nodes4q.data(), c->nodes4q.size() * sizeof(PtNode4Q)))) return rc;
-    if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
+    {   // the device copy of the triangle records carries the material with the id (PtTri::id): below 2^23 triangle slots a hit's
+        // triangle slot leaves room for it in the word the kernel keeps per hit, and id << 8 stays a positive int (same tie-break order)
+        c->tri_packed = c->bvh.tris.size() < ((size_t)1 << 23);
+        if (c->tri_packed) {
+            std::vector<PtTri> packed(c->bvh.tris);
+            for (PtTri& t : packed)
+                if (t.id != 0x7fffffff) t.id = (int32_t)(((uint32_t)t.id << 8) | (uint32_t)std::min(t.material + 1, 255));
+            if ((rc = upload(c, c->d_tris, packed.data(), packed.size() * sizeof(PtTri)))) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // `packed` is a local
+        } else if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
+    }
     if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
     for (void* p : c->d_textures) (void)hipFree(p);
     c->d_textures.clear();
@@ -524,6 +576,7 @@ int clone_scene(pt_ctx* dst, const pt_ctx* src)
     dst->materials = src->materials;
     dst->n_materials = src->n_materials;
     dst->material_texture = src->material_texture;
+    dst->uses_default_material = src->uses_default_material;
     dst->textures = src->textures;
     dst->env = src->env;
     dst->env_map = src->env_map;
@@ -653,10 +706,10 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     const int use_count = (c->count || (c->kernel == 2 && !P.nodes4)) ? 1 : 0;
     int variant = c->kernel == 2 && c->fallback && !use_count ? 3 : c->kernel;
     {
-        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         if (ge == hipErrorInvalidConfiguration && variant == 2 && !use_count) {
             variant = 3;
-            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         }
         if (ge == hipErrorInvalidConfiguration)
             return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
@@ -667,7 +720,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -687,7 +740,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         for (int nsd = 96; nsd <= 104 && !tiers; nsd += 8) { // 16 waves per CU up to 104 slots
             if (c->whole < 1 && (long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
             want_ns = nsd;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
             if (occ >= bpc && ns == nsd) {
                 tiers = true;
                 ring_grid = (int)std::max(1L, std::min(((long)c->n_pixels + ns - 1) / ns, capacity)); // what the ring schedule would launch
@@ -696,7 +749,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         }
         if (!tiers) {
             want_ns = 96;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     // the tier plan lives on the cost estimate: twice the samples (1/8 shard of C4 218 -> 201 ms; a throughput-bound frame gains nothing)

@@ -45,13 +45,17 @@ struct pt_ctx {
     std::vector<float> materials; // n * PT_MAT_STRIDE
     int n_materials = 0;
     std::vector<int32_t> material_texture;
+    uint32_t lobe_codes[PT_LOBE_TABLE] = {}; // pt_lobe_code per material (index = material + 1), upload_materials
+    uint32_t lobe_mask = 0;                 // lobes the scene's materials can sample: bit 0 diffuse, 1 clearcoat, 2 metallic, 3 glass (0: too many materials for the table)
+    bool uses_default_material = false;     // some mesh has material_index < 0
+    bool tri_packed = false;                // the device triangle records carry id << 8 | (material + 1) (upload_scene_to_device)
     std::vector<HostTexture> textures;
     pt_env env{};
     HostTexture env_map;
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes8, d_nodes4q, d_nodes4, d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket, d_tiers;
+    DevBuf d_nodes8, d_nodes4q, d_nodes4, d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket, d_tiers, d_lobe;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -61,7 +65,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, coop = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, quant = 1, express_permille = -1, ns_express = 8, whole = -1;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, coop = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, quant = 1, express_permille = -1, ns_express = 8, whole = -1, lobe_bins = -1;
     int tune[8] = {};
 
     void* comm = nullptr;   // ncclComm_t once pt_comm_init_rank / pt_group_create attached one (pt_comm.cpp)

@@ -73,6 +73,9 @@ using namespace ptd;
 #ifndef PT_WITH_QUANT
 #define PT_WITH_QUANT 0 // 64-byte quad nodes with 8-bit planes (option "quant")
 #endif
+#ifndef PT_PURE_MIN
+#define PT_PURE_MIN 24     // lanes the fullest lobe bin must fill for a hit pass over that bin alone (option "tune4")
+#endif
 #ifndef PT_RETIRE_MIN
 #define PT_RETIRE_MIN 16   // finished lanes that trigger a retire/refill pass (8..24 swept: +-1 %)
 #endif
@@ -867,10 +870,11 @@ static inline int pt_wave_lds_stack(int stack_entries, int group_entries)
     const int a = stack_entries < PT_LDS_STACK ? stack_entries : PT_LDS_STACK, b = (group_entries + 7) / 8;
     return a > b ? a : b;
 }
-static inline size_t pt_wave_lds_bytes(int stack_entries, int group_entries, int ns, int coop)
+// bins: the four lobe bins of the hit pass (ns bytes each) + the lobe-code table (LOBE-COHERENT HIT PASSES)
+static inline size_t pt_wave_lds_bytes(int stack_entries, int group_entries, int ns, int coop, int bins)
 {
     return (coop ? (size_t)PT_WAVE * sizeof(PtNode4) : 0) + ((size_t)pt_wave_lds_stack(stack_entries, group_entries) * PT_WAVE + (size_t)(L_NFIELDS + S_NFIELDS) * ns) * 4 +
-           (((size_t)3 * ns + 15) & ~(size_t)15);
+           (((size_t)(bins ? 7 : 3) * ns + (bins ? PT_LOBE_TABLE * 4 : 0) + 15) & ~(size_t)15);
 }
 static_assert(PT_GROUP_STACK <= 8 * PT_LDS_STACK, "a group's stack is eight columns of the LDS stack area");
 static inline size_t pt_wave_state_words(int stack_entries)
@@ -885,6 +889,10 @@ struct WaveCtx {
     uint32_t* lray;   // LDS
     uint32_t* lstate; // LDS
     uint8_t *rayq, *hitq, *missq;
+    uint8_t* binq;          // lobe bins of the hit pass: binq[b * ns + i], b = predicted lobe (LOBE-COHERENT HIT PASSES, below)
+    const uint32_t* ltab;   // LDS copy of the per-material lobe codes (PT_LOBE_TABLE words)
+    uint32_t bin_head, bin_count; // ring heads / fills of the four bins, one byte each (ns <= 255)
+    int binned;             // items in the bins (hit_count counts the unclassified ones in hitq)
     int ns;
     int ray_head, ray_count, hit_head, hit_count, miss_head, miss_count, n_dead;
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
@@ -925,17 +933,18 @@ enum { PICK_NONE = 0, PICK_HIT = 1, PICK_MISS = 2 };
 __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
 {
     const bool miss_ok = !w.miss_blocked;
-    if (w.hit_count >= w.full_batch) return PICK_HIT;
+    const int hits = w.hit_count + w.binned; // hits waiting for shading: not yet classified + in the lobe bins
+    if (hits >= w.full_batch) return PICK_HIT;
     if (miss_ok && w.miss_count >= w.full_batch) return PICK_MISS;
     if (w.ray_count < w.ray_low) {
         // the ray queue is about to run dry: a half-full shading pass is cheaper than idle traversal lanes (traversal is ~80 %
         // of a wave's time, shading ~12 %)
-        const bool h = w.hit_count >= w.min_batch, m = miss_ok && w.miss_count >= w.min_batch;
-        if (h && (!m || w.hit_count >= w.miss_count)) return PICK_HIT;
+        const bool h = hits >= w.min_batch, m = miss_ok && w.miss_count >= w.min_batch;
+        if (h && (!m || hits >= w.miss_count)) return PICK_HIT;
         if (m) return PICK_MISS;
     }
     if (starving) { // traversal has nothing to do: shade whatever is queued
-        if (w.hit_count > 0 && (w.hit_count >= w.miss_count || !miss_ok)) return PICK_HIT;
+        if (hits > 0 && (hits >= w.miss_count || !miss_ok)) return PICK_HIT;
         if (miss_ok && w.miss_count > 0) return PICK_MISS;
     }
     return PICK_NONE;
@@ -955,17 +964,88 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 #define GF(f, s) gstate[(f) * ns + (s)]
 #define GFF(f, s) __uint_as_float(gstate[(f) * ns + (s)])
-    uint8_t* q = IS_MISS ? w.missq : w.hitq;
-    int q_head = IS_MISS ? w.miss_head : w.hit_head;
-    int q_count = IS_MISS ? w.miss_count : w.hit_count;
-    const int n = q_count < PT_WAVE ? q_count : PT_WAVE;
+    int n;
+    int ps_slot = 0;
+    if (!IS_MISS && P.lobe_bins) {
+        // ---- LOBE-COHERENT HIT PASSES (round 4) ----------------------------------------------------------------------------------
+        // sample_disney picks ONE of four lobe bodies per hit from one draw against thresholds that depend on the material only
+        // (disney.cuh:31-63), and the bodies are long (GGX sampling + three Smith terms; GTR1 with pow / log; rough glass), so a hit
+        // pass over a mixed batch runs all of them back to back, each with the few lanes that chose it (C2: two bodies per pass at
+        // ~19 of 64 lanes each).  Here a hit is first CLASSIFIED - the material index travels with the hit (packed with the triangle
+        // id: tri_eval, retire), its lobe thresholds come from a 32-word LDS table, and the draw the shader will make next is peeked
+        // from the slot's RNG state without advancing it - and appended to the bin of its predicted lobe; the pass then shades ONE
+        // bin when that bin alone fills enough lanes (>= pure_min), else everything that is queued, bin by bin.  The shader itself is
+        // untouched and still decides everything from its own draw: a wrong prediction (9-bit thresholds; force_btdf, which needs
+        // the shading normal) costs divergence, never a different result, and a slot still has one item in flight, so the
+        // per-pixel RNG order (device.cu:226-243) is what it was.
+        uint32_t bh = w.bin_head, bc = w.bin_count;
+        while (w.hit_count > 0) { // classify the new arrivals (at most ns: two rounds)
+            const int nc = w.hit_count < PT_WAVE ? w.hit_count : PT_WAVE;
+            int lobe = -1, cslot = 0;
+            if (lane < nc) {
+                cslot = (int)w.hitq[w.wrap(w.hit_head + lane)];
+                const uint32_t code = w.ltab[LF(L_AZ, cslot) >> 24]; // material + 1 (0: material_data{} defaults), <= PT_LOBE_TABLE - 1
+                const uint32_t q9 = (16807u * GF(S_RNG, cslot) + 1013904223u) >> 23; // top 9 bits of the next draw (random.hpp:61-69)
+                const int prev = (int)((GF(S_PACK, cslot) >> 22) & 7u) - 1;
+                lobe = q9 < (code & 0x3ffu) ? kLobeMetallic : (q9 < ((code >> 10) & 0x3ffu) ? kLobeClearcoat : (q9 < ((code >> 20) & 0x3ffu) ? kLobeDiffuse : kLobeGlass));
+                if ((code & 0x80000000u) && prev == kLobeGlass) lobe = kLobeGlass; // inside a glass object: force_btdf (disney.cuh:39)
+                if (code & 0x40000000u) lobe = kLobeDiffuse;                       // emitter: no body runs at all - with the cheapest bin
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long mb = __ballot(lobe == b);
+                const int cnt_b = (int)((bc >> (8 * b)) & 0xffu), head_b = (int)((bh >> (8 * b)) & 0xffu);
+                if (lobe == b) w.binq[b * ns + w.wrap(w.wrap(head_b + cnt_b) + rank_in(mb))] = (uint8_t)cslot;
+                bc += (uint32_t)popc64(mb) << (8 * b);
+            }
+            w.hit_head = w.wrap(w.hit_head + nc);
+            w.hit_count -= nc;
+            w.binned += nc;
+        }
+        // the fullest bin alone if it fills pure_min lanes, else all bins in turn
+        const int c0 = (int)(bc & 0xffu), c1 = (int)((bc >> 8) & 0xffu), c2 = (int)((bc >> 16) & 0xffu), c3 = (int)(bc >> 24);
+        int best = 0, cbest = c0;
+        if (c1 > cbest) { best = 1; cbest = c1; }
+        if (c2 > cbest) { best = 2; cbest = c2; }
+        if (c3 > cbest) { best = 3; cbest = c3; }
+        const int pure_min = P.tune[4] > 0 ? P.tune[4] : PT_PURE_MIN;
+        const bool pure = cbest >= pure_min && cbest >= w.min_batch;
+        int t0 = c0, t1 = c1, t2 = c2, t3 = c3; // items taken from each bin
+        if (pure) {
+            t0 = best == 0 ? (c0 < PT_WAVE ? c0 : PT_WAVE) : 0; t1 = best == 1 ? (c1 < PT_WAVE ? c1 : PT_WAVE) : 0;
+            t2 = best == 2 ? (c2 < PT_WAVE ? c2 : PT_WAVE) : 0; t3 = best == 3 ? (c3 < PT_WAVE ? c3 : PT_WAVE) : 0;
+        } else {
+            int room = PT_WAVE;
+            t0 = t0 < room ? t0 : room; room -= t0;
+            t1 = t1 < room ? t1 : room; room -= t1;
+            t2 = t2 < room ? t2 : room; room -= t2;
+            t3 = t3 < room ? t3 : room;
+        }
+        n = t0 + t1 + t2 + t3;
+        if (lane < n) {
+            const int b = lane < t0 ? 0 : (lane < t0 + t1 ? 1 : (lane < t0 + t1 + t2 ? 2 : 3));
+            const int i = lane - (b > 0 ? t0 : 0) - (b > 1 ? t1 : 0) - (b > 2 ? t2 : 0);
+            ps_slot = (int)w.binq[b * ns + w.wrap((int)((bh >> (8 * b)) & 0xffu) + i)];
+        }
+        const uint32_t h0 = (uint32_t)w.wrap((int)(bh & 0xffu) + t0), h1 = (uint32_t)w.wrap((int)((bh >> 8) & 0xffu) + t1),
+                       h2 = (uint32_t)w.wrap((int)((bh >> 16) & 0xffu) + t2), h3 = (uint32_t)w.wrap((int)(bh >> 24) + t3);
+        w.bin_head = h0 | (h1 << 8) | (h2 << 16) | (h3 << 24);
+        w.bin_count = bc - ((uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24));
+        w.binned -= n;
+        if (COUNT) cn.lobe[7] += pure;
+    } else {
+        uint8_t* q = IS_MISS ? w.missq : w.hitq;
+        const int q_head = IS_MISS ? w.miss_head : w.hit_head;
+        const int q_count = IS_MISS ? w.miss_count : w.hit_count;
+        n = q_count < PT_WAVE ? q_count : PT_WAVE;
+        if (lane < n) ps_slot = (int)q[w.wrap(q_head + lane)];
+        if (IS_MISS) { w.miss_head = w.wrap(q_head + n); w.miss_count = q_count - n; } else { w.hit_head = w.wrap(q_head + n); w.hit_count = q_count - n; }
+    }
     const bool mine = lane < n;
     if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
-    int ps_slot = 0;
     bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
     int branch = -1; // COUNT: which branch of the hit shader the item took (0..3 sampled lobe, 4 emitter, 5 NaN retry)
     if (mine) {
-        ps_slot = (int)q[w.wrap(q_head + lane)];
         uint32_t pid = GF(S_PIX, ps_slot);
         const bool running = pid != PT_FRESH;
         uint32_t ticket = running ? PT_FRESH : GF(S_RNG, ps_slot);
@@ -993,7 +1073,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             if (COUNT) ++cn.rays;
             if (P.dbg_start && !P.cost_out) atomicAdd(P.dbg_start + (size_t)P.width * (size_t)P.height + (uint32_t)px + (uint32_t)P.width * (uint32_t)py, 1u); // diagnostics: rays per pixel
             v3 radiance;
-            const int tslot = IS_MISS ? -1 : (int)LF(L_AZ, ps_slot);
+            const int tslot = IS_MISS ? -1 : (int)(LF(L_AZ, ps_slot) & P.hit_slot_mask); // (the hit's material rides in the top byte: retire)
             const uint32_t scat0 = cn.scat;
             int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
             if (COUNT && !IS_MISS) branch = r == SR_RETRY ? 5 : (cn.scat != scat0 ? ps.lobe : 4);
@@ -1076,9 +1156,6 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         cn.lobe[14] += bodies >= 2;
         cn.lobe[15] += branches == 1;
     }
-    q_head = w.wrap(q_head + n);
-    q_count -= n;
-    if (IS_MISS) { w.miss_head = q_head; w.miss_count = q_count; } else { w.hit_head = q_head; w.hit_count = q_count; }
     const unsigned long long m_ray = __ballot(to_ray), m_hit = __ballot(to_hit), m_wait = __ballot(to_wait), m_dead = __ballot(died);
     if (to_ray) w.rayq[w.wrap(w.wrap(w.ray_head + w.ray_count) + rank_in(m_ray))] = (uint8_t)ps_slot;
     if (to_hit) w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_hit))] = (uint8_t)ps_slot;
@@ -1199,7 +1276,7 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
             if (fin_hit) {
                 LF(L_AX, pslot) = __float_as_uint(h.u);
                 LF(L_AY, pslot) = __float_as_uint(h.v);
-                LF(L_AZ, pslot) = (uint32_t)h.slot;
+                LF(L_AZ, pslot) = (uint32_t)h.slot | ((uint32_t)h.id << 24 & ~P.hit_slot_mask); // + material code of the hit (PtTri::id, packed)
                 w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_fh))] = (uint8_t)pslot;
             }
             if (fin_miss) w.missq[w.wrap(w.wrap(w.miss_head + w.miss_count) + rank_in(m_fm))] = (uint8_t)pslot;
@@ -1377,6 +1454,12 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.rayq = reinterpret_cast<uint8_t*>(lstate + S_NFIELDS * ns);
     w.hitq = w.rayq + ns;
     w.missq = w.hitq + ns;
+    w.binq = w.missq + ns;
+    uint32_t* ltab = reinterpret_cast<uint32_t*>(w.binq + (P.lobe_bins ? 4 * ns : 0)); // (4-byte aligned: ns is a multiple of 4 when the bins exist)
+    w.ltab = ltab;
+    if (P.lobe_bins && lane < PT_LOBE_TABLE) ltab[lane] = gp(P.lobe_codes)[lane];
+    w.bin_head = w.bin_count = 0u;
+    w.binned = 0;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtNode4* __restrict__ nodes4 = P.nodes4;
     const PtNode4Q* __restrict__ nodes4q = P.nodes4q;
@@ -1528,7 +1611,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                     if (fin_hit) {
                         LF(L_AX, pslot) = __float_as_uint(h.u);
                         LF(L_AY, pslot) = __float_as_uint(h.v);
-                        LF(L_AZ, pslot) = (uint32_t)h.slot;
+                        LF(L_AZ, pslot) = (uint32_t)h.slot | ((uint32_t)h.id << 24 & ~P.hit_slot_mask); // + material code of the hit (PtTri::id, packed)
                         w.hitq[w.wrap(w.wrap(w.hit_head + w.hit_count) + rank_in(m_fh))] = (uint8_t)pslot;
                     }
                     if (fin_miss) w.missq[w.wrap(w.wrap(w.miss_head + w.miss_count) + rank_in(m_fm))] = (uint8_t)pslot;
@@ -1726,7 +1809,7 @@ __global__ void __launch_bounds__(PT_BLOCK) pt_debug_kernel(const PtKernelParams
         Hit h;
         Counters cn;
         closest_hit<false>(P, stack, V(x[0], x[1], x[2]), V(x[3], x[4], x[5]), h, cn);
-        y[0] = h.slot >= 0 ? 1.0f : 0.0f; y[1] = h.t; y[2] = h.u; y[3] = h.v; y[4] = __int_as_float(h.slot >= 0 ? h.id : -1);
+        y[0] = h.slot >= 0 ? 1.0f : 0.0f; y[1] = h.t; y[2] = h.u; y[3] = h.v; y[4] = __int_as_float(h.slot >= 0 ? (P.hit_slot_mask != 0xffffffffu ? h.id >> 8 : h.id) : -1);
         break;
     }
     case PT_OP_FRAME: {
@@ -1938,7 +2021,7 @@ extern "C" hipError_t pt_launch_debug(const PtKernelParams* p, int op, const flo
 // Launch geometry of a render variant (1: lane per pixel, 2: wavefront kernel, 3: the wavefront kernel's 168-VGPR fallback
 // instance): block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for the wavefront kernel), per-block
 // global state words, registers, occupancy.  hipErrorInvalidConfiguration: the instance needs scratch (see below).
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int* block, size_t* lds_bytes, int* ns,
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int bins, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels)
 {
     const void* fn;
@@ -1953,9 +2036,11 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         fn = count ? (const void*)pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU>
                    : (variant == 3 ? (const void*)pt_render_wave_kernel<false, PT_FALLBACK_WAVES> : (const void*)pt_render_wave_kernel<false, PT_WAVES_PER_EU>);
         int n = want_ns < 16 ? 16 : (want_ns > 255 ? 255 : want_ns);
+        if (bins) n = (n + 3) & ~3; // the lobe-code table follows the byte queues: keep it word aligned
+        if (n > 252) n = 252;
         *block = PT_WAVE;
         *ns = n;
-        *lds_bytes = pt_wave_lds_bytes(stack_entries, group_entries, n, coop);
+        *lds_bytes = pt_wave_lds_bytes(stack_entries, group_entries, n, coop, bins);
         *lds_levels = pt_wave_lds_stack(stack_entries, group_entries);
         *state_words_per_block = pt_wave_state_words(stack_entries);
     }

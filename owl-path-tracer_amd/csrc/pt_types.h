@@ -69,7 +69,9 @@ static_assert(sizeof(PtNode8) == 256, "PtNode8 must be 256 bytes");
 // index_buffer: device.cu:42-61) + its global id (entity order, then face order).  48 bytes = 3 x dwordx4.
 struct PtTri {
     float p0[3], p1[3], p2[3];
-    int32_t id;
+    int32_t id;       // global triangle id (the closest hit's tie-break).  On the device, scenes below 2^23 triangle slots carry
+                      // id << 8 | min(material + 1, 255) here (same order: ids are unique) - the hit's material then reaches the
+                      // lobe bins of the hit pass without a fetch (pt_api.cpp, upload_scene_to_device)
     int32_t material; // copy of the shading record's material index: the material fetch need not wait for that record
     uint32_t pad;
 };
@@ -108,7 +110,7 @@ struct PtCounters {
     // group walk (sparse waves): {phases, iterations, sum of busy groups, sum of node groups, sum of leaf groups, rays traced, shader-clock cycles, unused}
     unsigned long long grp[8];
     // hit passes by sampled lobe (disney.cuh:9-13 order: 0 diffuse, 1 clearcoat, 2 metallic, 3 glass; 4 = emitter hit, 5 = NaN retry):
-    // [0..5] items, [8..13] hit passes in which at least one item took that branch (executions of that body), [14] passes with two or
+    // [0..5] items, [7] hit passes over one lobe bin alone, [8..13] hit passes in which at least one item took that branch (executions of that body), [14] passes with two or
     // more BSDF bodies, [15] passes whose items all took one branch
     unsigned long long lobes[16];
 };
@@ -174,4 +176,9 @@ struct PtKernelParams {
     int32_t groups;            // group walk: 0 = never, 1 = when a wave has few rays to trace (sparse wave), 2 = always (tests)
     int32_t coop;              // wavefront kernel, quad nodes: 1 = cooperative node fetch through an LDS staging area (node4_fetch_coop), 0 = per-lane loads
     int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
+    const uint32_t* lobe_codes; // PT_LOBE_TABLE words: lobe thresholds per material (pt_lobe_code), index = material + 1
+    int32_t lobe_bins;         // wavefront kernel: 1 = hit passes shade one predicted lobe at a time (pt_kernel.hip, LOBE-COHERENT HIT PASSES)
+    uint32_t hit_slot_mask;    // 0x00ffffff when PtTri::id is packed as id << 8 | (material + 1) (then a hit's material rides in the top byte of its
+                               // triangle slot), else 0xffffffff
 };
+#define PT_LOBE_TABLE 32       // materials + 1 the lobe bins can tell apart (scenes with more: no bins)
