@@ -104,6 +104,9 @@ typedef struct pt_stats {
      * 5 = NaN retry): [0..5] items, [7] passes that shaded one lobe bin alone (option "lobe_bins"), [8..13] passes in which at least one
      * item took that branch, [14] passes that ran two or more BSDF bodies, [15] passes whose items all took the same branch */
     uint64_t lobes[16];
+    /* counted renders, traversal (lane-steps): [0] quad-node steps that enter no child, [1] of those: the node lies beyond the best hit
+     * found so far, [2] unused, [3] leaf steps that do not improve the hit */
+    uint64_t trav[4];
 } pt_stats;
 
 /* ---- lifecycle (replaces init_owl_data/destroy_context: application.cpp:59-128, Main.cpp:30) ---- */
@@ -201,9 +204,9 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   level and running pixels up to which a wave counts as sparse);  "coop" / "quant": two validated experiments that are NOT in the product
  *   build (cooperative whole-line node fetch through an LDS staging area; 64-byte quad nodes with 8-bit planes) - builds made with
  *   EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1" contain them (default on there); elsewhere setting either to 1 returns PT_E_INVALID;
- *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" -1 (default: when the scene's materials can sample two or more
- *   different lobes, a hit pass shades the hits of ONE predicted lobe at a time) | 0 (never) | 1 (whenever the scene allows: < 2^23 triangles,
- *   < 32 materials), "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
+ *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" 0 (default) | 1 (a hit pass shades the hits of ONE predicted lobe at a
+ *   time whenever the scene allows: < 2^23 triangles, < 32 materials) | -1 (the same when the materials can sample two or more lobes) - built and
+ *   bit-exact, but it costs what it saves (profiles/r04_notes.md); "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
  *   the library does by itself when the 128-VGPR instance of a build needs scratch). */
 int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);

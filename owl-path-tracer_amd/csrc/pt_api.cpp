@@ -201,7 +201,8 @@ void fill_params(pt_ctx* c, PtKernelParams& P)
     for (int i = 0; i < 8; ++i) P.tune[i] = c->tune[i];
     P.lobe_codes = (const uint32_t*)c->d_lobe.p;
     P.hit_slot_mask = c->tri_packed ? 0x00ffffffu : 0xffffffffu;
-    // lobe bins (wavefront kernel): automatic = when the materials of the scene can sample two or more different lobes
+    // lobe bins (wavefront kernel; off by default - measured: they cost what they save, profiles/r04_notes.md): 1 = whenever the scene
+    // allows, -1 = when its materials can sample two or more different lobes
     const int n_lobes = __builtin_popcount(c->lobe_mask);
     P.lobe_bins = (c->kernel == 2 && c->tri_packed && c->lobe_mask != 0 && (c->lobe_bins > 0 || (c->lobe_bins < 0 && n_lobes >= 2))) ? 1 : 0;
 }
@@ -327,7 +328,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value && !(pt_kernel_features() & 2)) return fail(c, PT_E_INVALID, "option 'quant': this build has no quantised quad nodes (make EXTRA=-DPT_WITH_QUANT=1)");
         c->quant = value != 0;
     }
-    else if (k == "lobe_bins") c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // hit passes by predicted lobe: -1 automatic (default), 0 never, 1 whenever possible
+    else if (k == "lobe_bins") c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // hit passes by predicted lobe: 0 never (default), 1 whenever possible, -1 when the scene has two or more lobes
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -1052,6 +1053,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
             for (int i = 0; i < 32; ++i) c->stats.sched[i] = h.sched[i];
             for (int i = 0; i < 8; ++i) c->stats.groups[i] = h.grp[i];
             for (int i = 0; i < 16; ++i) c->stats.lobes[i] = h.lobes[i];
+            for (int i = 0; i < 4; ++i) c->stats.trav[i] = h.trav[i];
         }
     }
     *out = c->stats;

@@ -2,8 +2,18 @@
 #include "pt_bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#ifdef __linux__
+#include <sched.h>
+#endif
 
 #ifndef PT_SAH_BINS
 #define PT_SAH_BINS 64   // 16 -> 64 bins: 1.5 % fewer node visits on C4, 552 -> 541 ms (profiles/r03_notes.md)
@@ -30,24 +40,131 @@ struct Box {
     }
 };
 
+// A small fork-join pool for the build: run(n, fn) calls fn(i) for i in [0, n) on the pool's threads and the caller.
+class Pool {
+public:
+    explicit Pool(int threads)
+    {
+        for (int t = 1; t < threads; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    template <class F>
+    void run(int n, F&& fn)
+    {
+        if (n <= 0) return;
+        if (workers_.empty() || n == 1) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::function<void(int)> f = fn;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &f;
+            n_ = n;
+            next_.store(0);
+            left_ = (int)workers_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < n;) f(i);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            int n;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                f = fn_;
+                n = n_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--left_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, left_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
+// Threads the build may use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a container 16 of its 256 cores),
+// at most 32; PT_BUILD_THREADS overrides.
+int build_threads()
+{
+    if (const char* e = getenv("PT_BUILD_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1) return v > 64 ? 64 : v;
+    }
+    int n = (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const int q = (int)((atof(quota) + period / 2) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+#endif
+    return n < 1 ? 1 : (n > 32 ? 32 : n);
+}
+
+#ifndef PT_BUILD_PAR_MIN
+#define PT_BUILD_PAR_MIN 16384 // nodes with more triangles are split with all threads; smaller subtrees are tasks of their own
+#endif
+
+// Binned-SAH builder.  The tree, its node numbering (depth-first pre-order) and the triangle order do not depend on the number of
+// threads: nodes of more than PT_BUILD_PAR_MIN triangles are split one after the other with every thread binning a share of the
+// triangles (bins are min / max / counts: order independent) and taking part in a stable partition, the subtrees below them are
+// independent tasks that build into arrays of their own, and a last pass lays top nodes and subtrees out in the order the
+// recursion would have created them.  (Against the single-threaded builder of rounds 1-3: the same nodes; inside a leaf the
+// triangles may stand in another order - the top splits used std::partition - which no result depends on: closest hits break ties
+// by triangle id.)
 struct Builder {
     const float* pos;
     std::vector<Box> tb;        // per-triangle bounds
     std::vector<float> cen;     // per-triangle centroid * 3
     std::vector<int32_t> order; // permutation being partitioned
-    PtBvh* out;
+    std::vector<int32_t> scratch; // the parallel partition's second buffer
     int leaf_size, max_depth;
     float pad;
-    std::vector<int32_t> sweep_ids; // scratch of the exact sweep
-    std::vector<float> sweep_area;
+    Pool* pool = nullptr;
 
-    Box range_box(int lo, int hi) const
-    {
-        Box b;
-        b.reset();
-        for (int i = lo; i < hi; ++i) b.grow(tb[order[i]]);
-        return b;
-    }
+    struct Sub { // a subtree with local node indices
+        std::vector<PtNode> nodes;
+        int depth = 0, max_leaf = 0;
+    };
+
     static int levels_needed(int n, int leaf)
     {
         int l = 0;
@@ -64,32 +181,49 @@ struct Builder {
         });
     }
 
-    // returns child reference; depth = number of internal nodes on the path including the one created here
-    int32_t build(int lo, int hi, int depth, bool balanced)
+    // fn(chunk_lo, chunk_hi, chunk_index) over [lo, hi) - on the pool when `par`
+    template <class F>
+    void chunks(bool par, int lo, int hi, int* n_chunks, F&& fn)
     {
-        int n = hi - lo;
-        if (n <= leaf_size) {
-            out->max_leaf = std::max(out->max_leaf, n);
-            return ~((lo << 3) | n);
-        }
+        const int T = par ? pool->size() : 1;
+        *n_chunks = T;
+        if (T == 1) { fn(lo, hi, 0); return; }
+        const long n = hi - lo;
+        pool->run(T, [&](int t) { fn(lo + (int)(n * t / T), lo + (int)(n * (t + 1) / T), t); });
+    }
+
+    // Splits order[lo, hi) (more than leaf_size triangles): returns mid and the boxes of the two sides.
+    int split(int lo, int hi, int depth, bool& balanced, Box& l, Box& r, bool par)
+    {
+        const int n = hi - lo;
+        constexpr int MAXT = 64;
+        int nt = 1;
         Box cb;
         cb.reset();
-        for (int i = lo; i < hi; ++i) cb.grow(&cen[(size_t)order[i] * 3]);
-        int remaining = max_depth - depth; // internal levels still available below this node (this one included)
+        {
+            Box part[MAXT];
+            chunks(par, lo, hi, &nt, [&](int a, int b, int t) {
+                Box c;
+                c.reset();
+                for (int i = a; i < b; ++i) c.grow(&cen[(size_t)order[i] * 3]);
+                part[t] = c;
+            });
+            for (int t = 0; t < nt; ++t) cb.grow(part[t]);
+        }
+        const int remaining = max_depth - depth; // internal levels still available below this node (this one included)
         if (!balanced && levels_needed(n, leaf_size) >= remaining) balanced = true;
 
         int mid = -1;
         // (PT_SAH_LEAFCOUNT = 1 counts leaves, ceil(n / leaf_size), instead of triangles - a leaf step requests the records of a whole
         // leaf together - but fuller leaves cost more triangle tests than the saved node steps are worth: C4 +19 % tests, 541 -> 549 ms)
         auto leaves_of = [&](int c) { return PT_SAH_LEAFCOUNT ? (float)((c + leaf_size - 1) / leaf_size) : (float)c; };
+        bool have_boxes = false;
         if (!balanced && n <= PT_SAH_SWEEP) {
             // small node (most nodes are): the exact sweep - every split position along every axis, triangles sorted by centroid
             float best = INFINITY;
             int best_axis = -1, best_pos = -1;
-            std::vector<int32_t>& tmp = sweep_ids;
-            std::vector<float>& suffix = sweep_area;
-            tmp.resize((size_t)n);
-            suffix.resize((size_t)n + 1);
+            std::vector<int32_t> tmp((size_t)n);
+            std::vector<float> suffix((size_t)n + 1);
             for (int axis = 0; axis < 3; ++axis) {
                 if (!(cb.mx[axis] - cb.mn[axis] > 0.0f)) continue;
                 std::copy(order.begin() + lo, order.begin() + hi, tmp.begin());
@@ -116,48 +250,104 @@ struct Builder {
             }
         } else if (!balanced) {
             constexpr int NB = PT_SAH_BINS;
+            struct Bins { Box bb[3][NB]; int cnt[3][NB]; };
+            float lo_c[3], scale[3];
+            bool use[3];
+            for (int axis = 0; axis < 3; ++axis) {
+                const float ext = cb.mx[axis] - cb.mn[axis];
+                use[axis] = ext > 0.0f;
+                lo_c[axis] = cb.mn[axis];
+                scale[axis] = use[axis] ? (float)NB / ext : 0.0f;
+            }
+            // one pass over the triangles fills the bins of all three axes; with `par` every thread bins a share and the shares are
+            // merged (boxes by min / max, counts by addition: the result does not depend on the split)
+            std::vector<Bins> part((size_t)(par ? pool->size() : 1));
+            chunks(par, lo, hi, &nt, [&](int a, int b, int t) {
+                Bins& B = part[(size_t)t];
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int k = 0; k < NB; ++k) { B.bb[axis][k].reset(); B.cnt[axis][k] = 0; }
+                for (int i = a; i < b; ++i) {
+                    const int id = order[i];
+                    const Box& t_box = tb[id];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!use[axis]) continue;
+                        int k = (int)((cen[(size_t)id * 3 + axis] - lo_c[axis]) * scale[axis]);
+                        k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+                        B.bb[axis][k].grow(t_box);
+                        B.cnt[axis][k]++;
+                    }
+                }
+            });
+            Bins& B = part[0];
+            for (int t = 1; t < nt; ++t)
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int k = 0; k < NB; ++k) { B.bb[axis][k].grow(part[(size_t)t].bb[axis][k]); B.cnt[axis][k] += part[(size_t)t].cnt[axis][k]; }
             float best = INFINITY;
             int best_axis = -1, best_bin = -1;
             for (int axis = 0; axis < 3; ++axis) {
-                float lo_c = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
-                if (!(ext > 0.0f)) continue;
-                Box bb[NB];
-                int cnt[NB];
-                for (int b = 0; b < NB; ++b) { bb[b].reset(); cnt[b] = 0; }
-                float scale = (float)NB / ext;
-                for (int i = lo; i < hi; ++i) {
-                    int id = order[i];
-                    int b = (int)((cen[(size_t)id * 3 + axis] - lo_c) * scale);
-                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-                    bb[b].grow(tb[id]);
-                    cnt[b]++;
-                }
+                if (!use[axis]) continue;
                 float ra[NB];
                 int rc[NB];
                 Box acc;
                 acc.reset();
                 int c = 0;
-                for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; ra[b] = acc.half_area(); rc[b] = c; }
+                for (int k = NB - 1; k > 0; --k) { acc.grow(B.bb[axis][k]); c += B.cnt[axis][k]; ra[k] = acc.half_area(); rc[k] = c; }
                 acc.reset();
                 c = 0;
-                for (int b = 0; b < NB - 1; ++b) {
-                    acc.grow(bb[b]);
-                    c += cnt[b];
-                    if (c == 0 || rc[b + 1] == 0) continue;
-                    float cost = acc.half_area() * leaves_of(c) + ra[b + 1] * leaves_of(rc[b + 1]);
-                    if (cost < best) { best = cost; best_axis = axis; best_bin = b; }
+                for (int k = 0; k < NB - 1; ++k) {
+                    acc.grow(B.bb[axis][k]);
+                    c += B.cnt[axis][k];
+                    if (c == 0 || rc[k + 1] == 0) continue;
+                    float cost = acc.half_area() * leaves_of(c) + ra[k + 1] * leaves_of(rc[k + 1]);
+                    if (cost < best) { best = cost; best_axis = axis; best_bin = k; }
                 }
             }
             if (best_axis >= 0) {
-                float lo_c = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
-                float scale = (float)PT_SAH_BINS / ext;
-                auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](int32_t id) {
-                    int b = (int)((cen[(size_t)id * 3 + best_axis] - lo_c) * scale);
-                    b = b < 0 ? 0 : (b >= PT_SAH_BINS ? PT_SAH_BINS - 1 : b);
-                    return b <= best_bin;
-                });
-                mid = (int)(it - order.begin());
+                const float lc = lo_c[best_axis], sc = scale[best_axis];
+                auto goes_left = [&](int32_t id) {
+                    int k = (int)((cen[(size_t)id * 3 + best_axis] - lc) * sc);
+                    k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+                    return k <= best_bin;
+                };
+                if (par) {
+                    // all threads: a STABLE partition through `scratch` (each thread counts its share's left side, a prefix sum places the
+                    // shares, every thread writes its share) - the only order that does not depend on how the range was shared out
+                    int n_left[MAXT], start_l[MAXT], start_r[MAXT];
+                    chunks(true, lo, hi, &nt, [&](int a, int b, int t) {
+                        int c = 0;
+                        for (int i = a; i < b; ++i) c += goes_left(order[i]) ? 1 : 0;
+                        n_left[t] = c;
+                    });
+                    int total_left = 0;
+                    for (int t = 0; t < nt; ++t) total_left += n_left[t];
+                    int run_l = 0, run_r = total_left;
+                    for (int t = 0; t < nt; ++t) {
+                        const int a = lo + (int)((long)n * t / nt), b = lo + (int)((long)n * (t + 1) / nt);
+                        start_l[t] = run_l; start_r[t] = run_r;
+                        run_l += n_left[t]; run_r += (b - a) - n_left[t];
+                    }
+                    chunks(true, lo, hi, &nt, [&](int a, int b, int t) {
+                        int32_t* dl = scratch.data() + start_l[t];
+                        int32_t* dr = scratch.data() + start_r[t];
+                        for (int i = a; i < b; ++i) {
+                            const int32_t id = order[i];
+                            if (goes_left(id)) *dl++ = id; else *dr++ = id;
+                        }
+                    });
+                    chunks(true, lo, hi, &nt, [&](int a, int b, int) { std::memcpy(order.data() + a, scratch.data() + (a - lo), (size_t)(b - a) * 4); });
+                    mid = lo + total_left;
+                } else {
+                    auto it = std::partition(order.begin() + lo, order.begin() + hi, goes_left);
+                    mid = (int)(it - order.begin());
+                }
                 if (mid == lo || mid == hi) mid = -1;
+                else { // the sides' boxes are unions of the bins (every triangle is in exactly one)
+                    l.reset();
+                    r.reset();
+                    for (int k = 0; k <= best_bin; ++k) l.grow(B.bb[best_axis][k]);
+                    for (int k = best_bin + 1; k < NB; ++k) r.grow(B.bb[best_axis][k]);
+                    have_boxes = true;
+                }
             }
         }
         if (mid < 0) { // balanced / degenerate: object median along the widest centroid axis
@@ -168,13 +358,17 @@ struct Builder {
             mid = lo + n / 2;
             median_split(lo, hi, axis, mid);
         }
-        int idx = (int)out->nodes.size();
-        out->nodes.emplace_back();
-        out->depth = std::max(out->depth, depth);
-        Box l = range_box(lo, mid), r = range_box(mid, hi);
-        int32_t lc = build(lo, mid, depth + 1, balanced);
-        int32_t rc = build(mid, hi, depth + 1, balanced);
-        PtNode& nd = out->nodes[idx];
+        if (!have_boxes) {
+            l.reset();
+            r.reset();
+            for (int i = lo; i < mid; ++i) l.grow(tb[order[i]]);
+            for (int i = mid; i < hi; ++i) r.grow(tb[order[i]]);
+        }
+        return mid;
+    }
+
+    void store(PtNode& nd, const Box& l, const Box& r, int32_t lc, int32_t rc) const
+    {
         for (int a = 0; a < 3; ++a) {
             nd.lo[a][0] = l.mn[a] - pad; nd.hi[a][0] = l.mx[a] + pad;
             nd.lo[a][1] = r.mn[a] - pad; nd.hi[a][1] = r.mx[a] + pad;
@@ -182,7 +376,110 @@ struct Builder {
         nd.left = lc;
         nd.right = rc;
         nd.pad[0] = nd.pad[1] = 0;
+    }
+
+    // serial recursion into `dst` (local indices); depth = number of internal nodes on the path including the one created here
+    int32_t build(Sub& dst, int lo, int hi, int depth, bool balanced)
+    {
+        const int n = hi - lo;
+        if (n <= leaf_size) {
+            dst.max_leaf = std::max(dst.max_leaf, n);
+            return ~((lo << 3) | n);
+        }
+        Box l, r;
+        const int mid = split(lo, hi, depth, balanced, l, r, false);
+        const int idx = (int)dst.nodes.size();
+        dst.nodes.emplace_back();
+        dst.depth = std::max(dst.depth, depth);
+        const int32_t lc = build(dst, lo, mid, depth + 1, balanced);
+        const int32_t rc = build(dst, mid, hi, depth + 1, balanced);
+        store(dst.nodes[(size_t)idx], l, r, lc, rc);
         return idx;
+    }
+
+    // ---- the top of the tree: nodes split with all threads; what hangs below them is a task ----
+    struct Ref { int kind; int32_t v; }; // 0: leaf code, 1: top node, 2: task
+    struct Top { Box l, r; Ref lc, rc; int depth; };
+    struct Task { int lo, hi, depth; bool balanced; Sub sub; int32_t base = 0; };
+    std::vector<Top> top;
+    std::vector<Task> tasks;
+    int top_max_leaf = 0;
+
+    Ref build_top(int lo, int hi, int depth, bool balanced)
+    {
+        const int n = hi - lo;
+        if (n <= leaf_size) {
+            top_max_leaf = std::max(top_max_leaf, n);
+            return Ref{0, (int32_t)~((lo << 3) | n)};
+        }
+        if (n <= PT_BUILD_PAR_MIN) {
+            tasks.emplace_back();
+            Task& t = tasks.back();
+            t.lo = lo; t.hi = hi; t.depth = depth; t.balanced = balanced;
+            return Ref{2, (int32_t)tasks.size() - 1};
+        }
+        Box l, r;
+        const int mid = split(lo, hi, depth, balanced, l, r, true);
+        const int idx = (int)top.size();
+        top.emplace_back();
+        const Ref lc = build_top(lo, mid, depth + 1, balanced);
+        const Ref rc = build_top(mid, hi, depth + 1, balanced);
+        Top& t = top[(size_t)idx];
+        t.l = l; t.r = r; t.lc = lc; t.rc = rc; t.depth = depth;
+        return Ref{1, idx};
+    }
+
+    void run(int n_tris, PtBvh* out)
+    {
+        scratch.resize((size_t)n_tris);
+        const Ref root = build_top(0, n_tris, 1, false);
+        pool->run((int)tasks.size(), [&](int k) {
+            Task& t = tasks[(size_t)k];
+            t.sub.nodes.reserve((size_t)(t.hi - t.lo) / 3 + 16);
+            (void)build(t.sub, t.lo, t.hi, t.depth, t.balanced); // more than leaf_size triangles: its root is local node 0
+        });
+        // final indices in the order the serial recursion creates nodes: a node, its left subtree, its right subtree
+        std::vector<int32_t> final_of(top.size(), -1);
+        int32_t next = 0;
+        {
+            std::vector<Ref> st{root};
+            while (!st.empty()) {
+                const Ref r = st.back();
+                st.pop_back();
+                if (r.kind == 1) {
+                    final_of[(size_t)r.v] = next++;
+                    st.push_back(top[(size_t)r.v].rc); // left first
+                    st.push_back(top[(size_t)r.v].lc);
+                } else if (r.kind == 2) {
+                    tasks[(size_t)r.v].base = next;
+                    next += (int32_t)tasks[(size_t)r.v].sub.nodes.size();
+                }
+            }
+        }
+        auto resolve = [&](const Ref& r) { return r.kind == 0 ? r.v : (r.kind == 1 ? final_of[(size_t)r.v] : tasks[(size_t)r.v].base); };
+        out->nodes.resize((size_t)next);
+        out->depth = 0;
+        out->max_leaf = top_max_leaf;
+        for (size_t i = 0; i < top.size(); ++i) {
+            const Top& t = top[i];
+            store(out->nodes[(size_t)final_of[i]], t.l, t.r, resolve(t.lc), resolve(t.rc));
+            out->depth = std::max(out->depth, t.depth);
+        }
+        pool->run((int)tasks.size(), [&](int k) {
+            const Task& t = tasks[(size_t)k];
+            PtNode* dst = out->nodes.data() + t.base;
+            for (size_t i = 0; i < t.sub.nodes.size(); ++i) {
+                PtNode nd = t.sub.nodes[i];
+                if (nd.left >= 0) nd.left += t.base;
+                if (nd.right >= 0) nd.right += t.base;
+                dst[i] = nd;
+            }
+        });
+        for (const Task& t : tasks) {
+            out->depth = std::max(out->depth, t.sub.depth);
+            out->max_leaf = std::max(out->max_leaf, t.sub.max_leaf);
+        }
+        out->root = resolve(root);
     }
 };
 
@@ -568,26 +865,35 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
     if (n_tris <= 0) return;
     leaf_size = std::max(1, std::min(7, leaf_size));
     max_depth = std::max(2, std::min((int)PT_MAX_STACK, max_depth));
+    Pool pool(n_tris > 4 * PT_BUILD_PAR_MIN ? build_threads() : 1); // small scenes: one thread, no pool
     Builder b;
     b.pos = positions;
-    b.out = out;
+    b.pool = &pool;
     b.leaf_size = leaf_size;
     b.max_depth = max_depth;
     b.tb.resize(n_tris);
     b.cen.resize((size_t)n_tris * 3);
     b.order.resize(n_tris);
+    const int T = pool.size();
+    std::vector<Box> part((size_t)T);
+    pool.run(T, [&](int t) {
+        Box all;
+        all.reset();
+        for (int i = (int)((long)n_tris * t / T); i < (int)((long)n_tris * (t + 1) / T); ++i) {
+            const float* p = positions + (size_t)i * 9;
+            Box tbx;
+            tbx.reset();
+            tbx.grow(p); tbx.grow(p + 3); tbx.grow(p + 6);
+            b.tb[i] = tbx;
+            for (int a = 0; a < 3; ++a) b.cen[(size_t)i * 3 + a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
+            b.order[i] = i;
+            all.grow(tbx);
+        }
+        part[(size_t)t] = all;
+    });
     Box all;
     all.reset();
-    for (int i = 0; i < n_tris; ++i) {
-        const float* p = positions + (size_t)i * 9;
-        Box t;
-        t.reset();
-        t.grow(p); t.grow(p + 3); t.grow(p + 6);
-        b.tb[i] = t;
-        for (int a = 0; a < 3; ++a) b.cen[(size_t)i * 3 + a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
-        b.order[i] = i;
-        all.grow(t);
-    }
+    for (const Box& p : part) all.grow(p);
     float ext = 0.0f;
     for (int a = 0; a < 3; ++a) {
         ext = std::max(ext, all.mx[a] - all.mn[a]);
@@ -597,20 +903,21 @@ void pt_bvh_build(const float* positions, int32_t n_tris, int leaf_size, int max
     // report (its geometric error is orders of magnitude below 1e-5 * extent), so closest-hit is topology-independent.
     b.pad = ext * 1e-5f;
     out->pad = b.pad;
-    out->nodes.reserve((size_t)n_tris);
-    out->root = b.build(0, n_tris, 1, false);
+    b.run(n_tris, out);
 #if PT_BVH_ROTATIONS > 0
     rotate_tree(out, max_depth, PT_BVH_ROTATIONS);
 #endif
     out->tris.resize(n_tris);
-    for (int i = 0; i < n_tris; ++i) {
-        int id = b.order[i];
-        PtTri& t = out->tris[i];
-        std::memcpy(t.p0, positions + (size_t)id * 9, 36);
-        t.id = id;
-        t.material = -1; // filled in by the caller that owns the shading records (pt_api.cpp)
-        t.pad = 0;
-    }
+    pool.run(T, [&](int t) {
+        for (int i = (int)((long)n_tris * t / T); i < (int)((long)n_tris * (t + 1) / T); ++i) {
+            const int id = b.order[i];
+            PtTri& tr = out->tris[i];
+            std::memcpy(tr.p0, positions + (size_t)id * 9, 36);
+            tr.id = id;
+            tr.material = -1; // filled in by the caller that owns the shading records (pt_api.cpp)
+            tr.pad = 0;
+        }
+    });
 }
 
 bool pt_bvh_from_hierarchy(const float* positions, int32_t n_tris, const int32_t* child, const float* box, const int32_t* count, const uint32_t* order, int32_t root,

@@ -96,6 +96,7 @@ struct Counters {
     uint32_t grp[6] = {};    // wave-uniform census of the group walk: phases, iterations, busy groups, node groups, leaf groups, rays
     unsigned long long grp_cyc = 0;
     uint32_t lobe[16] = {};  // wave-uniform census of the hit passes by sampled lobe (PtCounters::lobes)
+    uint32_t cull[4] = {};   // per lane: quad steps that enter no child, of those: node beyond the best hit; [2] scratch; [3] leaf steps that do not improve the hit
 };
 
 // Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
@@ -264,7 +265,7 @@ __device__ __forceinline__ void node_step(const PtNode* __restrict__ nodes, uint
 // conservative (pt_types.h).  Empty slots are masked by their reference.
 template <int STRIDE, int LDS_ENTRIES, bool COOP, bool QUANT = false>
 __device__ __forceinline__ void node4_step(const void* __restrict__ nodes4, const uint32_t* rec, int rot, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest,
-                                           int& cur, int& sp)
+                                           int& cur, int& sp, uint32_t* cull_census = nullptr)
 {
     f32x4 lx, ly, lz, hx, hy, hz, cf;
     if (QUANT) {
@@ -310,6 +311,11 @@ __device__ __forceinline__ void node4_step(const void* __restrict__ nodes4, cons
         tf = tf * pad;
         tn[2 * p] = ta; tn[2 * p + 1] = tb;
         hit[2 * p] = ta <= tf.x; hit[2 * p + 1] = tb <= tf.y;
+        if (cull_census) { // instrumented instance: would the slot be hit without the bound of the best hit so far?
+            const float fa = fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmax_hw(t0z.x, t1z.x)) * 1.0000004f;
+            const float fb = fmin_hw(fmin_hw(fmax_hw(t0x.y, t1x.y), fmax_hw(t0y.y, t1y.y)), fmax_hw(t0z.y, t1z.y)) * 1.0000004f;
+            cull_census[2] |= (ta <= fa ? 1u : 0u) | (tb <= fb ? 1u : 0u);
+        }
     }
     const int r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
     if (QUANT) { hit[0] = hit[0] && r0 != -1; hit[1] = hit[1] && r1 != -1; hit[2] = hit[2] && r2 != -1; hit[3] = hit[3] && r3 != -1; }
@@ -321,6 +327,11 @@ __device__ __forceinline__ void node4_step(const void* __restrict__ nodes4, cons
     const bool in_b = m23 < m01; // the nearest hit is in slot pair {2, 3}
     const int nearc = in_b ? r23 : r01;
     const bool any = hit[0] || hit[1] || hit[2] || hit[3];
+    if (cull_census) { // [0] steps that enter nothing, [1] ... although the ray crosses one of the boxes: the node lies beyond the best hit
+        cull_census[0] += any ? 0u : 1u;
+        cull_census[1] += (!any && cull_census[2]) ? 1u : 0u;
+        cull_census[2] = 0u;
+    }
     // push order: the two slots of the OTHER pair first, the nearest's sibling last (popped first): siblings share a parent box, so
     // the sibling is usually the next nearest.  Three pushes at most.
     // (of the other pair, the farther slot first)
@@ -755,6 +766,11 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
         atomicAdd(&P.counters->grp[6], cn.grp_cyc);
 #pragma unroll
         for (int k = 0; k < 16; ++k) atomicAdd(&P.counters->lobes[k], (unsigned long long)cn.lobe[k]);
+    }
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long x = k == 2 ? 0ull : cn.cull[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters->trav[k], x);
     }
     for (int k = 0; k < 4; ++k) {
         unsigned long long x = cn.depth[k];
@@ -1687,7 +1703,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                             else if (cur >= 0) {
                                 if (COUNT) cn.nodes += nodes4 ? 2 : 1;
                                 if (quant) node4_step<PT_WAVE, 0x7fffffff, false, true>(nodes4q, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
-                                else if (nodes4) node4_step<PT_WAVE, 0x7fffffff, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp);
+                                else if (nodes4) node4_step<PT_WAVE, 0x7fffffff, false>(nodes4, nullptr, 0, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.cull : nullptr);
                                 else if (COUNT) node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth); // the one-level walk exists in the instrumented instance only
                                 PT_STASH_LEAF(0x7fffffff);
                             }
@@ -1718,7 +1734,9 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                         const uint32_t code = ~(uint32_t)pend;
                         const int firstt = (int)(code >> 3), count = (int)(code & 7u);
                         if (COUNT) cn.tris += (uint32_t)count;
+                        const float t_before = h.t;
                         leaf_test(tris, firstt, count, o, d, h);
+                        if (COUNT) cn.cull[3] += h.t == t_before ? 1u : 0u;
                         if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
                             pend = cur;
                             if (sp > 0) {

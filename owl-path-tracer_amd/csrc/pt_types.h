@@ -113,6 +113,10 @@ struct PtCounters {
     // [0..5] items, [7] hit passes over one lobe bin alone, [8..13] hit passes in which at least one item took that branch (executions of that body), [14] passes with two or
     // more BSDF bodies, [15] passes whose items all took one branch
     unsigned long long lobes[16];
+    // traversal census (lane-steps): [0] quad-node steps that enter no child, [1] of those: the ray does cross a child's box, but beyond the
+    // best hit so far (an entry distance kept with the stack entry would have skipped the fetch), [2] unused, [3] leaf steps that do not
+    // improve the hit
+    unsigned long long trav[4];
 };
 
 #define PT_MAX_TAIL_CHUNKS 20

@@ -51,13 +51,14 @@ class Stats(C.Structure):
                 ("block", C.c_int32), ("grid", C.c_int32), ("stack_entries", C.c_int32),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64), ("scatters", C.c_uint64),
                 ("env_misses", C.c_uint64), ("nan_retries", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8), ("reduce_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_variant", C.c_int32), ("express_pixels", C.c_int32), ("whole_pixels", C.c_int32), ("prepass_spp", C.c_int32), ("lobes", C.c_uint64 * 16)]
+                ("n_triangles", C.c_uint64), ("bvh_build_ms", C.c_double), ("sched", C.c_uint64 * 32), ("prepass_ms", C.c_double), ("groups", C.c_uint64 * 8), ("reduce_ms", C.c_double), ("d2h_ms", C.c_double), ("kernel_variant", C.c_int32), ("express_pixels", C.c_int32), ("whole_pixels", C.c_int32), ("prepass_spp", C.c_int32), ("lobes", C.c_uint64 * 16), ("trav", C.c_uint64 * 4)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["sched"] = list(self.sched)
         d["groups"] = list(self.groups)
         d["lobes"] = list(self.lobes)
+        d["trav"] = list(self.trav)
         return d
 
 

@@ -372,19 +372,21 @@ def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
     want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(**env), W, H, 24, 16, want_rgba8=True, want_counters=True)
     assert_bitwise(rgb, want, "material coverage")
     np.testing.assert_array_equal(rgba, want8)
-    # lobe-coherent hit passes (round 4): this scene samples all four lobes, so the bins are on by default; the image must not depend
-    # on them - off, and on with every threshold for a pass over one bin alone (tune4: 1 = always .. 200 = never), counted build too
+    # lobe-coherent hit passes (round 4, option "lobe_bins", off by default): this scene samples all four lobes; the image must not
+    # depend on the bins - on with every threshold for a pass over one bin alone (tune4: 1 = always .. 200 = never), counted build too
     gpu.set_option("count", 1)
+    gpu.set_option("lobe_bins", 1)
     gpu.render(cam, W, H, 24, 16)
     lb = gpu.stats()["lobes"]
+    gpu.set_option("lobe_bins", 0)
     gpu.set_option("count", 0)
     assert all(lb[i] > 0 for i in range(5)) and lb[7] > 0, lb  # four lobes + emitter hits; some passes ran one bin alone
     assert gpu.stats()["scatters"] == cnt["scatters"] and gpu.stats()["rays"] == cnt["rays"]
-    for bins, pure_min in ((0, 0), (1, 1), (1, 8), (1, 40), (1, 200)):
+    for bins, pure_min in ((-1, 0), (1, 1), (1, 8), (1, 40), (1, 200)):
         gpu.set_option("lobe_bins", bins)
         gpu.set_option("tune4", pure_min)
         got, _ = gpu.render(cam, W, H, 24, 16)
-        gpu.set_option("lobe_bins", -1)
+        gpu.set_option("lobe_bins", 0)
         gpu.set_option("tune4", 0)
         assert_bitwise(got, want, "lobe bins %d, pure_min %d" % (bins, pure_min))
     # environment map path (device.cu:23-39,138-139): same scene under a synthetic 8-bit lat-long map

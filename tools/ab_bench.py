@@ -80,6 +80,7 @@ def main():
         W, H, spp = 512, 512, int(opts.get("spp", 256))
         c = sc["camera"]
         cam = B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+    t_up = time.perf_counter()
     if which == "c5":
         gi = [n for n, _, _ in mats].index("Ground")
         envmap = procedural.rgbe_to_ldr_rgba8(procedural.synthetic_sky_rgbe(2048, 1024))
@@ -89,6 +90,7 @@ def main():
         ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(use_auto=True, intensity=1.0))
     else:
         ctx.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    upload_ms = (time.perf_counter() - t_up) * 1e3
     if "shard_rank" in opts:
         ctx.set_pixel_shard(int(opts["shard_rank"]), int(opts.get("shard_world", 8)), int(opts.get("shard_tile", 16)))
     for k, v in opts.items():
@@ -196,6 +198,11 @@ def main():
         cen["rays_per_sample"] = round(cs["rays"] / max(1, cs["samples"]), 3)
         cen["env_misses"] = cs["env_misses"]
         cen["lobes"] = lobe_census(cs)
+        tv = cs["trav"]
+        quad_lane_steps = max(1, cen["node_lanes"])  # lanes in node rounds x ~steps per round: use nodes / 2 (a quad step counts two node units)
+        cen["trav"] = {"quad_lane_steps": cs["nodes"] // 2, "no_child_entered": tv[0], "of_those_beyond_best_hit": tv[1], "leaf_lane_steps": cen["tri_lanes"], "leaf_steps_without_improvement": tv[3],
+                       "share_no_child": round(tv[0] / max(1, cs["nodes"] // 2), 4), "share_cullable": round(tv[1] / max(1, cs["nodes"] // 2), 4),
+                       "share_leaf_no_improvement": round(tv[3] / max(1, cen["tri_lanes"]), 4)}
         g = cs["groups"]
         cen["groups"] = {"phases": g[0], "iters": g[1], "iters/phase": round(g[1] / max(1, g[0]), 2), "busy_groups/iter": round(g[2] / max(1, g[1]), 2),
                          "node_groups/iter": round(g[3] / max(1, g[1]), 2), "leaf_groups/iter": round(g[4] / max(1, g[1]), 2), "rays": g[5],
@@ -217,6 +224,7 @@ def main():
         print(json.dumps({"laps_ms": ctx.read_laps()}))
     print(json.dumps({"lib": os.path.basename(B.LIB_PATH), "scene": which, "opts": opts, "kernel_ms_min": round(min(ms), 2), "kernel_ms_med": round(float(np.median(ms)), 2),
                       "Msamples/s": round(W * H * spp / min(ms) / 1e3, 1), "prepass_ms": round(st.get("prepass_ms", 0.0), 2), "vgprs": st["vgprs"], "lds": st["lds_bytes"], "grid": st["grid"], "block": st["block"],
-                      "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": round(st["bvh_build_ms"], 2)}))
+                      "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": round(st["bvh_build_ms"], 2), "upload_scene_ms": round(upload_ms, 1)}))
 
-main()
+if __name__ == "__main__":
+    main()
