@@ -639,12 +639,112 @@ static void layout_align_leaves(PtBvh* b, int align)
     b->tris.swap(out);
 }
 
+// Quad nodes by surface area (round 4): starting from the two children of a binary node, the internal slot with the largest box is
+// replaced by its two children until four slots are used (as pt_bvh_collapse8 does for eight).  Against the fixed two-level collapse
+// below: no slot stays empty next to a leaf child while another slot could still be opened, and a large child is opened in preference
+// to a small one - fewer quad nodes on a ray's way (expected visits = sum over quad nodes of area(slot box) / area(root)).
+static void collapse4_by_area(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4, int* depth4)
+{
+    struct Slot { float lo[3], hi[3]; int32_t ref; };
+    auto area = [](const Slot& s) {
+        const float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto child_slot = [&](const PtNode& nd, int side) {
+        Slot s;
+        for (int a = 0; a < 3; ++a) { s.lo[a] = nd.lo[a][side]; s.hi[a] = nd.hi[a][side]; }
+        s.ref = side ? nd.right : nd.left;
+        return s;
+    };
+    struct Item { int32_t node2; int32_t idx4; int depth; };
+    std::vector<Item> todo;
+    out->emplace_back();
+    todo.push_back({b.root, 0, 1});
+    *root4 = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        *depth4 = std::max(*depth4, it.depth);
+        Slot slots[4];
+        int n = 0;
+        {
+            const PtNode& nd = b.nodes[(size_t)it.node2];
+            for (int side = 0; side < 2; ++side)
+                if ((side ? nd.right : nd.left) != -1) slots[n++] = child_slot(nd, side);
+        }
+        while (n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < n; ++k)
+                if (slots[k].ref >= 0) {
+                    const float ar = area(slots[k]);
+                    if (ar > best_area) { best_area = ar; best = k; }
+                }
+            if (best < 0) break;
+            const PtNode& cn = b.nodes[(size_t)slots[best].ref];
+            // the two children stay next to each other (the kernel pushes a slot's pair partner last: siblings are usually next nearest)
+            for (int k = n; k > best + 1; --k) slots[k] = slots[k - 1];
+            slots[best] = child_slot(cn, 0);
+            slots[best + 1] = child_slot(cn, 1);
+            ++n;
+        }
+        PtNode4 q;
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 4; ++k) q.lo[a][k] = q.hi[a][k] = INFINITY; // never hit (empty slot)
+        for (int k = 0; k < 4; ++k) { q.child[k] = -1; q.pad[k] = 0; }
+        for (int k = 0; k < n; ++k) {
+            for (int a = 0; a < 3; ++a) { q.lo[a][k] = slots[k].lo[a]; q.hi[a][k] = slots[k].hi[a]; }
+            if (slots[k].ref >= 0) {
+                const int32_t idx = (int32_t)out->size();
+                out->emplace_back();
+                q.child[k] = idx;
+                todo.push_back({slots[k].ref, idx, it.depth + 1});
+            } else {
+                q.child[k] = slots[k].ref;
+            }
+        }
+        (*out)[(size_t)it.idx4] = q;
+    }
+}
+
+// expected quad-node visits of a long random ray that crosses the root box: sum over the quad nodes of area(box of the slot that refers to
+// the node) / area(root box); leaf visits likewise (diagnostics: pt_debug_quad_info)
+void pt_bvh_quad_cost(const std::vector<PtNode4>& nodes4, int32_t root4, double* node_visits, double* leaf_visits)
+{
+    *node_visits = *leaf_visits = 0.0;
+    if (root4 < 0 || nodes4.empty()) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const PtNode4& r = nodes4[(size_t)root4];
+    for (int k = 0; k < 4; ++k)
+        if (r.child[k] != -1)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], r.lo[a][k]); hi[a] = std::max(hi[a], r.hi[a][k]); }
+    const double ra = (double)(hi[0] - lo[0]) * (hi[1] - lo[1]) + (double)(hi[1] - lo[1]) * (hi[2] - lo[2]) + (double)(hi[2] - lo[2]) * (hi[0] - lo[0]);
+    if (!(ra > 0.0)) return;
+    double nv = 1.0, lv = 0.0;
+    for (const PtNode4& q : nodes4)
+        for (int k = 0; k < 4; ++k) {
+            if (q.child[k] == -1) continue;
+            const double dx = q.hi[0][k] - q.lo[0][k], dy = q.hi[1][k] - q.lo[1][k], dz = q.hi[2][k] - q.lo[2][k];
+            const double ar = (dx * dy + dy * dz + dz * dx) / ra;
+            if (q.child[k] >= 0) nv += ar; else lv += ar;
+        }
+    *node_visits = nv;
+    *leaf_visits = lv;
+}
+
+#ifndef PT_COLLAPSE4_BY_AREA
+#define PT_COLLAPSE4_BY_AREA 1
+#endif
 void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4, int* depth4)
 {
     out->clear();
     *root4 = b.root;
     *depth4 = 0;
     if (b.root < 0) return; // empty scene or a leaf as root: no quad nodes
+    {
+        const char* e = getenv("PT_COLLAPSE4_BY_AREA"); // A/B switch (tools/): 0 = the fixed two-level collapse of rounds 2-3
+        if (e ? e[0] != '0' : PT_COLLAPSE4_BY_AREA) { collapse4_by_area(b, out, root4, depth4); return; }
+    }
     struct Item { int32_t node2; int32_t idx4; int depth; };
     std::vector<Item> todo;
     out->emplace_back();

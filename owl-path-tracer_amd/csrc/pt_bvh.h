@@ -28,6 +28,9 @@ void pt_bvh_layout(PtBvh* bvh, int sibling_pairs, int leaf_align);
 // binary root reference: leaf code or -1), depth4 = deepest chain of quad nodes (the traversal stack needs 3 * depth4 entries).
 void pt_bvh_collapse4(const PtBvh& bvh, std::vector<PtNode4>* out, int32_t* root4, int* depth4);
 
+// Expected visits of a long random ray through the root box: quad nodes / leaf slots (surface-area metric; diagnostics).
+void pt_bvh_quad_cost(const std::vector<PtNode4>& nodes4, int32_t root4, double* node_visits, double* leaf_visits);
+
 // Host mirror of the kernel's traversal over the product BVH (validation only, never on the render path).
 bool pt_bvh_closest_hit_host(const PtBvh& bvh, const float org[3], const float dir[3], float tmin, float tmax, float* t, float* u,
                              float* v, int32_t* prim);
