@@ -733,7 +733,7 @@ void pt_bvh_quad_cost(const std::vector<PtNode4>& nodes4, int32_t root4, double*
 }
 
 #ifndef PT_COLLAPSE4_BY_AREA
-#define PT_COLLAPSE4_BY_AREA 1
+#define PT_COLLAPSE4_BY_AREA 0 // measured (profiles/r04_notes.md): 2-10 % fewer quad steps, no time gained (C5 +1.5 %): off
 #endif
 void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4, int* depth4)
 {
