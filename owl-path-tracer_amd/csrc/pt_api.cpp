@@ -1,6 +1,7 @@
 // pt_api.cpp -- implementation of the C-ABI declared in include/mi355pt.h (host side, HIP runtime).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -358,6 +359,14 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
             if (material_texture[i] >= n_textures) return fail(c, PT_E_INVALID, "material %d: texture index %d out of range (%d textures)", i, material_texture[i], n_textures);
     c->have_scene = false;
     if (!c->host_only) HIP_TRY(c, hipSetDevice(c->device));
+    // PT_UPLOAD_TRACE=1: phase times of this call on stderr
+    const bool trace = getenv("PT_UPLOAD_TRACE") && getenv("PT_UPLOAD_TRACE")[0] == '1';
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (trace) fprintf(stderr, "pt_upload_scene: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
 
     // ---- flatten entities to one record per triangle, global order = entity order then face order ----
     size_t n_tris = 0;
@@ -381,23 +390,36 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         if (ms.texture_index >= n_textures) return fail(c, PT_E_INVALID, "mesh %d: texture index %d out of range", m, ms.texture_index);
         if (ms.texture_index >= 0 && ms.material_index >= 0 && !material_texture) c->material_texture[ms.material_index] = ms.texture_index;
         const bool textured = ms.texture_index >= 0;
-        for (int t = 0; t < ms.n_triangles; ++t, ++g) {
-            PtShade& sh = c->shade[g];
-            sh.material = ms.material_index;
-            for (int k = 0; k < 3; ++k) {
-                int32_t vi = ms.indices[(size_t)t * 3 + k];
-                if (vi < 0 || vi >= ms.n_vertices) return fail(c, PT_E_INVALID, "mesh %d: vertex index out of range", m);
-                // the reference traps on an out-of-bounds normal/texcoord fetch (macros.hpp:5-11)
-                if (!ms.normals || vi >= ms.n_normals) return fail(c, PT_E_INVALID, "mesh %d: no normal for vertex %d", m, vi);
-                if (textured && (!ms.texcoords || vi >= ms.n_texcoords)) return fail(c, PT_E_INVALID, "mesh %d: no texcoord for vertex %d", m, vi);
-                std::memcpy(&pos[g * 9 + (size_t)k * 3], ms.vertices + (size_t)vi * 3, 12);
-                float* nd = k == 0 ? sh.n0 : (k == 1 ? sh.n1 : sh.n2);
-                std::memcpy(nd, ms.normals + (size_t)vi * 3, 12);
-                if (ms.texcoords && vi < ms.n_texcoords) std::memcpy(&sh.tc[k * 2], ms.texcoords + (size_t)vi * 2, 8);
+        // (the triangles of a large mesh are flattened by all build threads; bad: 1 = vertex index, 2 = normal, 3 = texcoord, + 4 * vertex)
+        std::atomic<long long> bad{0};
+        const size_t g0 = g;
+        pt_parallel_ranges((size_t)ms.n_triangles, [&](size_t t_lo, size_t t_hi) {
+            for (size_t t = t_lo; t < t_hi; ++t) {
+                PtShade& sh = c->shade[g0 + t];
+                sh.material = ms.material_index;
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t vi = ms.indices[t * 3 + (size_t)k];
+                    if (vi < 0 || vi >= ms.n_vertices) { bad.store(1 + 4ll * vi); return; }
+                    // the reference traps on an out-of-bounds normal/texcoord fetch (macros.hpp:5-11)
+                    if (!ms.normals || vi >= ms.n_normals) { bad.store(2 + 4ll * vi); return; }
+                    if (textured && (!ms.texcoords || vi >= ms.n_texcoords)) { bad.store(3 + 4ll * vi); return; }
+                    std::memcpy(&pos[(g0 + t) * 9 + (size_t)k * 3], ms.vertices + (size_t)vi * 3, 12);
+                    float* nd = k == 0 ? sh.n0 : (k == 1 ? sh.n1 : sh.n2);
+                    std::memcpy(nd, ms.normals + (size_t)vi * 3, 12);
+                    if (ms.texcoords && vi < ms.n_texcoords) std::memcpy(&sh.tc[k * 2], ms.texcoords + (size_t)vi * 2, 8);
+                }
             }
+        });
+        if (const long long b = bad.load()) {
+            const int what = (int)(b & 3), vi = (int)(b >> 2);
+            if (what == 1) return fail(c, PT_E_INVALID, "mesh %d: vertex index out of range", m);
+            if (what == 2) return fail(c, PT_E_INVALID, "mesh %d: no normal for vertex %d", m, vi);
+            return fail(c, PT_E_INVALID, "mesh %d: no texcoord for vertex %d", m, vi);
         }
+        g += (size_t)ms.n_triangles;
     }
 
+    phase("flatten entities");
     // ---- BVH (replaces owlGroupBuildAccel, application.cpp:135-139) ----
     auto t0 = std::chrono::steady_clock::now();
     const int leaf_sz = std::max(1, std::min(7, c->leaf_size));
@@ -477,25 +499,31 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     c->stats.bvh_depth = (uint64_t)c->bvh.depth;
     c->stats.n_triangles = n_tris;
     if (c->bvh.depth > PT_MAX_STACK) return fail(c, PT_E_LIMIT, "BVH depth %d exceeds %d", c->bvh.depth, PT_MAX_STACK);
+    phase("BVH build");
     pt_bvh_layout(&c->bvh, c->node_pairs, c->leaf_align);
     c->stats.bvh_nodes = c->bvh.nodes.size();
     pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
+    phase("quad nodes");
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
     if (!(pt_kernel_features() & 2) || c->nodes4.empty() || !pt_bvh_quantize4(c->nodes4, &c->nodes4q, c->quant_reach)) c->nodes4q.clear();
     pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8);
     if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
+    phase("oct nodes");
     { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
         const size_t n_slots = c->bvh.tris.size();
         std::vector<PtShade> by_leaf(n_slots);
-        for (size_t i = 0; i < n_slots; ++i) {
-            const int32_t id = c->bvh.tris[i].id;
-            if (id == 0x7fffffff) { std::memset(&by_leaf[i], 0, sizeof(PtShade)); by_leaf[i].material = -1; continue; }
-            by_leaf[i] = c->shade[(size_t)id];
-            c->bvh.tris[i].material = by_leaf[i].material;
-        }
+        pt_parallel_ranges(n_slots, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const int32_t id = c->bvh.tris[i].id;
+                if (id == 0x7fffffff) { std::memset(&by_leaf[i], 0, sizeof(PtShade)); by_leaf[i].material = -1; continue; }
+                by_leaf[i] = c->shade[(size_t)id];
+                c->bvh.tris[i].material = by_leaf[i].material;
+            }
+        });
         c->shade.swap(by_leaf);
     }
 
+    phase("shading records");
     // ---- textures, materials, environment ----
     c->textures.assign((size_t)n_textures, HostTexture{});
     for (int i = 0; i < n_textures; ++i) {
@@ -510,6 +538,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         const int urc = pti::upload_scene_to_device(c);
         if (urc) return urc;
     }
+    phase("textures, upload to HBM");
     c->have_scene = true;
     return PT_OK;
 }
@@ -530,14 +559,10 @@ int upload_scene_to_device(pt_ctx* c)
     if ((rc = upload(c, c->d_nodes4q, c->nodes4q.data(), c->nodes4q.size() * sizeof(PtNode4Q)))) return rc;
     {   // the device copy of the triangle records carries the material with the id (PtTri::id): below 2^23 triangle slots a hit's
         // triangle slot leaves room for it in the word the kernel keeps per hit, and id << 8 stays a positive int (same tie-break order)
+        // (packed on the device after the copy: pt_pack_tri_ids_kernel)
         c->tri_packed = c->bvh.tris.size() < ((size_t)1 << 23);
-        if (c->tri_packed) {
-            std::vector<PtTri> packed(c->bvh.tris);
-            for (PtTri& t : packed)
-                if (t.id != 0x7fffffff) t.id = (int32_t)(((uint32_t)t.id << 8) | (uint32_t)std::min(t.material + 1, 255));
-            if ((rc = upload(c, c->d_tris, packed.data(), packed.size() * sizeof(PtTri)))) return rc;
-            HIP_TRY(c, hipStreamSynchronize(c->stream)); // `packed` is a local
-        } else if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
+        if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
+        if (c->tri_packed) HIP_TRY(c, pt_launch_pack_tri_ids((PtTri*)c->d_tris.p, (long long)c->bvh.tris.size(), c->stream));
     }
     if ((rc = upload(c, c->d_shade, c->shade.data(), c->shade.size() * sizeof(PtShade)))) return rc;
     for (void* p : c->d_textures) (void)hipFree(p);

@@ -139,6 +139,19 @@ int build_threads()
     return n < 1 ? 1 : (n > 32 ? 32 : n);
 }
 
+} // namespace
+
+// fn(begin, end) over [0, n) in one contiguous share per thread (pt_api.cpp: flattening and re-ordering of the per-triangle records)
+void pt_parallel_ranges(size_t n, const std::function<void(size_t, size_t)>& fn)
+{
+    const int T = n >= 65536 ? build_threads() : 1;
+    if (T == 1) { fn(0, n); return; }
+    Pool pool(T);
+    pool.run(T, [&](int t) { fn(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); });
+}
+
+namespace {
+
 #ifndef PT_BUILD_PAR_MIN
 #define PT_BUILD_PAR_MIN 16384 // nodes with more triangles are split with all threads; smaller subtrees are tasks of their own
 #endif

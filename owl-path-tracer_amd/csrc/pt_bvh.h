@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "pt_types.h"
@@ -27,6 +28,9 @@ void pt_bvh_layout(PtBvh* bvh, int sibling_pairs, int leaf_align);
 // Two-level collapse of the binary tree into quad nodes (PtNode4, pt_types.h).  root4 = 0 when the root is an internal node (else the
 // binary root reference: leaf code or -1), depth4 = deepest chain of quad nodes (the traversal stack needs 3 * depth4 entries).
 void pt_bvh_collapse4(const PtBvh& bvh, std::vector<PtNode4>* out, int32_t* root4, int* depth4);
+
+// fn(begin, end) over [0, n), one contiguous share per build thread (small n: the caller's thread alone)
+void pt_parallel_ranges(size_t n, const std::function<void(size_t, size_t)>& fn);
 
 // Expected visits of a long random ray through the root box: quad nodes / leaf slots (surface-area metric; diagnostics).
 void pt_bvh_quad_cost(const std::vector<PtNode4>& nodes4, int32_t root4, double* node_visits, double* leaf_visits);

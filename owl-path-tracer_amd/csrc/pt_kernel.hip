@@ -2018,6 +2018,23 @@ extern "C" hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long
     return hipGetLastError();
 }
 
+// PtTri::id -> id << 8 | min(material + 1, 255) on the device copy of the triangle records (pt_api.cpp, upload_scene_to_device): the
+// host keeps its records unpacked, and packing there would mean a second 48-byte-per-triangle copy on every upload.
+__global__ void __launch_bounds__(256) pt_pack_tri_ids_kernel(PtTri* __restrict__ tris, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t id = tris[i].id, m = tris[i].material;
+    if (id != 0x7fffffff) tris[i].id = (int32_t)(((uint32_t)id << 8) | (uint32_t)(m + 1 < 255 ? m + 1 : 255));
+}
+
+extern "C" hipError_t pt_launch_pack_tri_ids(PtTri* tris, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_pack_tri_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tris, n);
+    return hipGetLastError();
+}
+
 // The parameter block of a wavefront launch, stored by a one-thread kernel: kernel arguments are captured when the launch is
 // enqueued, so the host copy may be reused for the next launch at once (a hipMemcpyAsync from pageable memory is only safe while the
 // runtime stages it at enqueue time).

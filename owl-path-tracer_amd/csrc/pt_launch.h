@@ -21,6 +21,7 @@ hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int gro
 int pt_debug_block(void);
 int pt_kernel_features(void);
 hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream);
+hipError_t pt_launch_pack_tri_ids(PtTri* tris, long long n, hipStream_t stream);
 hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long long n, hipStream_t stream);
 // pt_lbvh.hip
 size_t pt_lbvh_workspace_bytes(int n);

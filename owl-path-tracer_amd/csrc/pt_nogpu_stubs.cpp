@@ -21,5 +21,6 @@ hipError_t pt_lbvh_build_device(const float*, int, int, void*, size_t, PtNode*, 
 size_t pt_ploc_workspace_bytes(int) { return 16; }
 hipError_t pt_ploc_build_device(const float*, int, int, void*, size_t, int*, float*, int*, uint32_t*, int32_t*, int32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_store_params(const PtKernelParams*, PtKernelParams*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t pt_launch_pack_tri_ids(PtTri*, long long, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_pack_rgba8(const float*, uint32_t*, long long, hipStream_t) { return hipErrorNotSupported; }
 }
