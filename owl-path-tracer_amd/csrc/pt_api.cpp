@@ -318,7 +318,6 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "fallback") c->fallback = value != 0; // force the wavefront kernel's 168-VGPR fallback instance (tests)
     else if (k == "express_permille") c->express_permille = (int)(value < 0 ? -1 : (value > 500 ? 500 : value)); // -1: automatic
     else if (k == "whole") c->whole = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // whole-pixel schedule by cost class when every pixel can have a path slot: -1 the plan decides (default), 0 never, 1 always
-    else if (k == "express_mode") c->express_mode = value == 1 ? 1 : 0; // 0: express pixels in waves of their own; 1: whole-pixel tickets every wave takes first (needs express_permille > 0)
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "coop") { // wavefront kernel + quad nodes: cooperative node fetch through LDS - only in builds made with -DPT_WITH_COOP=1 (default on there)
@@ -923,21 +922,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         const int nse = std::max(1, std::min(c->ns_express, ns));
         uint64_t want = (uint64_t)((double)c->n_pixels * permille / 1000.0);
         const int capacity = c->num_cus * bpc;
-        // express_mode 1 (pt_kernel.hip, WHOLE PIXELS FIRST): no waves of their own - the most expensive pixels are whole-pixel tickets
-        // that every wave takes first; as many as the option says, at most one per path slot of the launch
-        const bool first = c->express_mode == 1 && c->express_permille > 0;
-        if (first) {
-            want = std::min<uint64_t>(want, (uint64_t)rgrid * (uint64_t)ns);
-            if (want > 0 && want < c->n_pixels) {
-                n_express = (uint32_t)want;
-                express_waves = 0;
-                P.ns_express = ns;
-                P.express_first = 1;
-            }
-        } else {
         want = std::min<uint64_t>(want, (uint64_t)std::max(rgrid / 8, std::min(capacity / 2, capacity - rgrid)) * (uint64_t)nse);
-        }
-        if (!first && want > 0 && want < c->n_pixels) {
+        if (want > 0 && want < c->n_pixels) {
             n_express = (uint32_t)want;
             express_waves = (int)((want + (uint64_t)nse - 1) / (uint64_t)nse);
             P.ns_express = nse;
@@ -973,7 +959,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_tickets = c->n_pixels;
                 P.n_express = 0;
                 P.express_waves = 0;
-                P.express_first = 0;
                 P.tiers = nullptr;
             } else {
                 P.chunk_spp = main_sc.chunk;
@@ -981,7 +966,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
                 P.n_full = main_sc.n_full;
                 P.n_express = n_express;
                 P.express_waves = express_waves;
-                P.express_first = (c->express_mode == 1 && n_express != 0) ? 1 : 0;
                 P.n_tickets = (c->n_pixels - n_express) * (uint32_t)n_chunks;
                 if (tiers) { // the plan decides on the device: pixels by cost class (then none of the above is used), or the ring schedule as prepared
                     P.tiers = (const uint32_t*)c->d_tiers.p;

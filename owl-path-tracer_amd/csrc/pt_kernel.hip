@@ -617,7 +617,6 @@ struct WaveTier {      // where this wave's pixels come from (wave-uniform)
     uint32_t* counter; // tier schedule: the ticket counter of the wave's tier, else null
     uint32_t q0, count; // ... and the tier's queue entries [q0, q0 + count)
     bool express;      // ring schedule: this wave renders express pixels only
-    bool whole_first;  // ring schedule, P.express_first: this wave still tries the whole-pixel tickets (the express counter) before the chunk tickets
 };
 // EXPRESS PIXELS (round 3).  A pixel is one sequential chain of rays (device.cu:226-243) and a frame whose pixels all run at once -
 // one rank's shard of a multi-GPU frame, a small image - ends when its most expensive pixel does: chain length x per-ray turnaround,
@@ -638,29 +637,17 @@ struct WaveTier {      // where this wave's pixels come from (wave-uniform)
 // hands out pixels, not chunks - a slot keeps its pixel for all samples - and every wave serves ONE cost class of the cost-ordered
 // queue with as few pixels as that class needs to finish with the others: pt_plan_tiers_kernel (below) turns the histogram of the
 // counting sort into a tier table on the device, and a wave looks up its tier by workgroup index.
-// WHOLE PIXELS FIRST (round 4, P.express_first).  In a launch with a few pixels per path slot (one rank's shard at world 2-4) the ring
-// schedule's laps hold the expensive pixels back: a pixel that finished its first chunk cannot start its second before every
-// first-chunk ticket of the launch is handed out, so the longest chains run their last chunks after everything else is done (world 2:
-// 99 % of the pixels finish between 60 and 70 % of the frame time, the rest of the time belongs to a few thousand expensive pixels).
-// With express_first the n_express most expensive pixels are whole-pixel tickets that EVERY wave takes before any chunk ticket: they
-// start at t = 0 in dense waves and never wait for a lap; the cheaper pixels fill in behind them through the rings as before.
-// `dry` (out): the whole-pixel tickets are gone - the wave stops asking (pt_render_wave_kernel clears WaveTier::whole_first).
-__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, const WaveTier& tier, bool& dry)
+__device__ __forceinline__ uint32_t take_ticket(const PtKernelParams& P, const WaveTier& tier)
 {
     if (tier.counter != nullptr) {
         const uint32_t e = take_agent(tier.counter);
         return e < tier.count ? PT_EXPRESS | (tier.q0 + e) : PT_NO_TICKET;
     }
-    if (tier.whole_first) {
-        const uint32_t e = take_agent(P.queue_head + 64);
-        if (e < P.n_express) return PT_EXPRESS | e;
-        dry = true;
-    }
     if (!tier.express) {
         const uint32_t t = take_agent(P.queue_head);
         if (t < P.n_tickets) return t;
     }
-    if (P.n_express && !P.express_first) {
+    if (P.n_express) {
         const uint32_t e = take_agent(P.queue_head + 64); // the express counter: 256 bytes after the queue head
         if (e < P.n_express) return PT_EXPRESS | e;
     }
@@ -1072,7 +1059,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     }
     const bool mine = lane < n;
     if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
-    bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false, dry = false;
+    bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
     int branch = -1; // COUNT: which branch of the hit shader the item took (0..3 sampled lobe, 4 emitter, 5 NaN retry)
     if (mine) {
         uint32_t pid = GF(S_PIX, ps_slot);
@@ -1118,7 +1105,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                         gp(P.cost_out)[(uint32_t)px + (uint32_t)P.width * (uint32_t)py] = pt_cost_class((uint32_t)wall_clock64() - cost);
                         cost = 0u;
                     }
-                    ticket = take_ticket(P, w.tier, dry); // in flight while finish_chunk stores the pixel's state
+                    ticket = take_ticket(P, w.tier); // in flight while finish_chunk stores the pixel's state
                     finish_chunk(P, chunk, px, py, ps.rng, color);
                     have_pixel = false;
                     ended = true;
@@ -1129,7 +1116,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         }
         if (need_gen) {
             if (!have_pixel) {
-                if (ticket == PT_FRESH) ticket = take_ticket(P, w.tier, dry);
+                if (ticket == PT_FRESH) ticket = take_ticket(P, w.tier);
                 if (ticket == PT_NO_TICKET) {
                     died = true;
                 } else if (start_chunk(P, ticket, chunk, px, py, ps.rng, color)) {
@@ -1194,7 +1181,6 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     w.miss_count += popc64(m_wait);
     w.n_dead += popc64(m_dead);
     w.n_run += popc64(__ballot(started)) - popc64(__ballot(ended));
-    if (w.tier.whole_first && __ballot(dry) != 0ull) w.tier.whole_first = false;
     if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? n : 0; } // [17]: rays shaded after the queue ran dry (wind-down)
     // a pass that only polled unpublished tickets must not be repeated before the wave has done something else
     w.miss_blocked = IS_MISS && n > 0 && popc64(m_wait) == n;
@@ -1510,7 +1496,6 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.tier.counter = nullptr;
     w.tier.q0 = w.tier.count = 0u;
     w.tier.express = P.n_express != 0u && blockIdx.x < (uint32_t)P.express_waves;
-    w.tier.whole_first = P.express_first != 0 && P.n_express != 0u;
     int ns_live = w.tier.express ? (P.ns_express < ns ? P.ns_express : ns) : ns; // slots that ever get a pixel
     if (P.tiers != nullptr) { // tier schedule: which cost class does this workgroup serve, and how many of its pixels at a time?
         const uint32_t PT_AS1* tt = gp(P.tiers);
@@ -1531,7 +1516,6 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
             }
         }
         w.tier.express = ns_live <= PT_GROUP_MAX_RAYS;
-        w.tier.whole_first = false;
         }
     }
     if (w.tier.express) __builtin_amdgcn_s_setprio(3);

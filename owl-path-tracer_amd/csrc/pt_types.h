@@ -167,7 +167,6 @@ struct PtKernelParams {
     uint32_t n_express;        // the first n_express entries of the (cost-ordered) queue are express pixels (pt_kernel.hip, take_ticket); 0: none
     int32_t express_waves;     // workgroups [0, express_waves) render express pixels only,
     int32_t ns_express;        // ... this many at a time
-    int32_t express_first;     // 1: no express waves - every wave takes the n_express whole-pixel tickets before any chunk ticket (pt_kernel.hip, WHOLE PIXELS FIRST)
     const uint32_t* tiers;     // != null: whole-pixel schedule by cost class (pt_kernel.hip, TIERS): the table pt_plan_tiers_kernel wrote for this launch
     int32_t ring_grid;         // ... and if that table is empty (the plan chose the ring schedule): workgroups beyond this one have nothing to do
     int32_t timeline;          // diagnostics: record the chunk timeline (pt_debug_read_laps); costs one more atomic per finished pixel
