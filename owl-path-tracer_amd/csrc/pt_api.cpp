@@ -276,7 +276,7 @@ void pt_destroy(pt_ctx* c)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)pt_comm_destroy(c);
-        DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4q, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
+        DevBuf* bufs[] = {&c->d_nodes8, &c->d_nodes4, &c->d_nodes, &c->d_tris, &c->d_shade, &c->d_materials, &c->d_texdesc, &c->d_env, &c->d_pixels, &c->d_heads,
                           &c->d_rng, &c->d_accum, &c->d_out, &c->d_out8, &c->d_counters, &c->d_dbg_in, &c->d_dbg_out, &c->d_slots, &c->d_laps, &c->d_ring, &c->d_params, &c->d_cost, &c->d_sorted, &c->d_sort_scratch, &c->d_dbg_start, &c->d_bucket, &c->d_tiers, &c->d_lobe};
         for (DevBuf* b : bufs) release(*b);
         for (void* p : c->d_textures) (void)hipFree(p);
@@ -320,15 +320,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "whole") c->whole = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // whole-pixel schedule by cost class when every pixel can have a path slot: -1 the plan decides (default), 0 never, 1 always
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
-    else if (k == "coop") { // wavefront kernel + quad nodes: cooperative node fetch through LDS - only in builds made with -DPT_WITH_COOP=1 (default on there)
-        if (value && !(pt_kernel_features() & 1)) return fail(c, PT_E_INVALID, "option 'coop': this build has no cooperative node fetch (make EXTRA=-DPT_WITH_COOP=1)");
-        c->coop = value != 0;
-    }
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
-    else if (k == "quant") { // wavefront kernel: 64-byte quad nodes with 8-bit planes - only in builds made with -DPT_WITH_QUANT=1 (default on there)
-        if (value && !(pt_kernel_features() & 2)) return fail(c, PT_E_INVALID, "option 'quant': this build has no quantised quad nodes (make EXTRA=-DPT_WITH_QUANT=1)");
-        c->quant = value != 0;
-    }
     else if (k == "lobe_bins") c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // hit passes by predicted lobe: 0 never (default), 1 whenever possible, -1 when the scene has two or more lobes
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
@@ -504,7 +496,6 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
     phase("quad nodes");
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
-    if (!(pt_kernel_features() & 2) || c->nodes4.empty() || !pt_bvh_quantize4(c->nodes4, &c->nodes4q, c->quant_reach)) c->nodes4q.clear();
     pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8);
     if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
     phase("oct nodes");
@@ -555,7 +546,6 @@ int upload_scene_to_device(pt_ctx* c)
     if ((rc = upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(PtNode)))) return rc;
     if ((rc = upload(c, c->d_nodes4, c->nodes4.data(), c->nodes4.size() * sizeof(PtNode4)))) return rc;
     if ((rc = upload(c, c->d_nodes8, c->nodes8.data(), c->nodes8.size() * sizeof(PtNode8)))) return rc;
-    if ((rc = upload(c, c->d_nodes4q, c->nodes4q.data(), c->nodes4q.size() * sizeof(PtNode4Q)))) return rc;
     {   // the device copy of the triangle records carries the material with the id (PtTri::id): below 2^23 triangle slots a hit's
         // triangle slot leaves room for it in the word the kernel keeps per hit, and id << 8 stays a positive int (same tie-break order)
         // (packed on the device after the copy: pt_pack_tri_ids_kernel)
@@ -593,8 +583,6 @@ int clone_scene(pt_ctx* dst, const pt_ctx* src)
     dst->nodes4 = src->nodes4;
     dst->root4 = src->root4;
     dst->depth4 = src->depth4;
-    dst->nodes4q = src->nodes4q;
-    std::memcpy(dst->quant_reach, src->quant_reach, sizeof(dst->quant_reach));
     dst->nodes8 = src->nodes8;
     dst->root8 = src->root8;
     dst->depth8 = src->depth8;
@@ -706,12 +694,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         P.nodes4 = (const PtNode4*)c->d_nodes4.p;
         P.root = c->root4;
         P.stack_entries = 3 * c->depth4 + 1;
-        P.coop = (pt_kernel_features() & 1) ? c->coop : 0;
-        // the same quad tree as 64-byte records with 8-bit planes - unless the camera is so far outside the scene that rounding its
-        // distance to a node's frame could eat the one-cell margin of the boxes (pt_bvh_quantize4); secondary rays start on surfaces
-        bool cam_ok = true;
-        for (int a = 0; a < 3; ++a) cam_ok = cam_ok && cam->origin[a] >= c->quant_reach[a][0] && cam->origin[a] <= c->quant_reach[a][1];
-        if ((pt_kernel_features() & 2) && c->quant && !c->nodes4q.empty() && !P.coop && cam_ok) P.nodes4q = (const PtNode4Q*)c->d_nodes4q.p;
     }
     if (c->kernel == 2 && c->groups && !c->nodes8.empty()) { // group walk of sparse waves (oct nodes)
         P.nodes8 = (const PtNode8*)c->d_nodes8.p;
@@ -732,10 +714,10 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     const int use_count = (c->count || (c->kernel == 2 && !P.nodes4)) ? 1 : 0;
     int variant = c->kernel == 2 && c->fallback && !use_count ? 3 : c->kernel;
     {
-        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         if (ge == hipErrorInvalidConfiguration && variant == 2 && !use_count) {
             variant = 3;
-            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         }
         if (ge == hipErrorInvalidConfiguration)
             return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
@@ -746,7 +728,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -766,7 +748,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         for (int nsd = 96; nsd <= 104 && !tiers; nsd += 8) { // 16 waves per CU up to 104 slots
             if (c->whole < 1 && (long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
             want_ns = nsd;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
             if (occ >= bpc && ns == nsd) {
                 tiers = true;
                 ring_grid = (int)std::max(1L, std::min(((long)c->n_pixels + ns - 1) / ns, capacity)); // what the ring schedule would launch
@@ -775,7 +757,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         }
         if (!tiers) {
             want_ns = 96;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.coop, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     // the tier plan lives on the cost estimate: twice the samples (1/8 shard of C4 218 -> 201 ms; a throughput-bound frame gains nothing)

@@ -799,67 +799,6 @@ void pt_bvh_collapse4(const PtBvh& b, std::vector<PtNode4>* out, int32_t* root4,
     }
 }
 
-bool pt_bvh_quantize4(const std::vector<PtNode4>& nodes4, std::vector<PtNode4Q>* out, float reach[3][2])
-{
-    out->clear();
-    if (nodes4.empty()) return false;
-    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (const PtNode4& q : nodes4)
-        for (int k = 0; k < 4; ++k) {
-            if (q.child[k] == -1) continue;
-            for (int a = 0; a < 3; ++a) {
-                if (!std::isfinite(q.lo[a][k]) || !std::isfinite(q.hi[a][k])) return false;
-                mn[a] = std::min(mn[a], (double)q.lo[a][k]);
-                mx[a] = std::max(mx[a], (double)q.hi[a][k]);
-            }
-        }
-    // Ray origins are on surfaces (inside the scene box) or at the camera, which the caller keeps within 1.5 extents of the box:
-    // |o - origin| <= 4 extents on any axis.  The kernel rounds (o - origin) once: error <= 2^-24 of that; a cell of at least 2^-21 x
-    // (4 extents) makes it less than an eighth of a cell - the boxes carry a whole cell of margin.
-    double s_min[3];
-    for (int a = 0; a < 3; ++a) {
-        const double ext = std::max(mx[a] - mn[a], 1e-30);
-        reach[a][0] = (float)(mn[a] - 1.5 * ext);
-        reach[a][1] = (float)(mx[a] + 1.5 * ext);
-        const double span = 4.0 * ext + std::max(std::fabs(mn[a]), std::fabs(mx[a])) * 0.0; // origin distances, not coordinates, are rounded
-        s_min[a] = span * std::ldexp(1.0, -21);
-    }
-    out->resize(nodes4.size());
-    for (size_t i = 0; i < nodes4.size(); ++i) {
-        const PtNode4& q = nodes4[i];
-        PtNode4Q r;
-        std::memset(&r, 0, sizeof(r));
-        for (int a = 0; a < 3; ++a) {
-            double lo = INFINITY, hi = -INFINITY;
-            for (int k = 0; k < 4; ++k)
-                if (q.child[k] != -1) { lo = std::min(lo, (double)q.lo[a][k]); hi = std::max(hi, (double)q.hi[a][k]); }
-            if (!(hi >= lo)) { lo = hi = 0.0; } // a node without children cannot occur; keep the record well formed
-            // cell: the smallest power of two s with (hi - lo) / s <= 250 (room for the margin cells in 0..254), not below s_min, and
-            // large enough that origin = k * s is exact in float (|k| < 2^23)
-            double s = std::max((hi - lo) / 250.0, s_min[a]);
-            s = std::max(s, std::max(std::fabs(lo), std::fabs(hi)) * std::ldexp(1.0, -22));
-            int e = 0;
-            (void)std::frexp(s, &e); // s = m * 2^e, m in [0.5, 1)
-            s = std::ldexp(1.0, e);  // >= s
-            if (!(s > 0.0) || !std::isfinite(s) || (double)(float)s != s) return false;
-            const double org = (std::floor(lo / s) - 1.0) * s; // a multiple of s, one to two cells below the node's box
-            if ((double)(float)org != org) return false;
-            r.origin[a] = (float)org;
-            r.scale[a] = (float)s;
-            for (int k = 0; k < 4; ++k) {
-                if (q.child[k] == -1) continue;
-                const double ql = std::floor(((double)q.lo[a][k] - org) / s) - 1.0, qh = std::ceil(((double)q.hi[a][k] - org) / s) + 1.0;
-                if (ql < 0.0 || qh > 255.0) return false; // cannot happen with the room left above; never emit a box that is too small
-                r.q[a][k] = (uint8_t)ql;
-                r.q[3 + a][k] = (uint8_t)qh;
-            }
-        }
-        for (int k = 0; k < 4; ++k) r.child[k] = q.child[k];
-        (*out)[i] = r;
-    }
-    return true;
-}
-
 void pt_bvh_collapse8(const PtBvh& b, int wide_leaves, std::vector<PtNode8>* out, int32_t* root8, int* depth8)
 {
     out->clear();

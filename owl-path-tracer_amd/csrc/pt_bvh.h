@@ -52,8 +52,3 @@ void pt_bvh_collapse8(const PtBvh& bvh, int wide_leaves, std::vector<PtNode8>* o
 // pt_bvh_build.  Returns false (out untouched in a usable way) if the tree is deeper than max_depth: the caller then builds on the host.
 bool pt_bvh_from_hierarchy(const float* positions, int32_t n_tris, const int32_t* child, const float* box, const int32_t* count, const uint32_t* order, int32_t root,
                            int leaf_size, int max_depth, PtBvh* out);
-
-// The quad nodes as 64-byte records with 8-bit planes in a frame per node (PtNode4Q, pt_types.h).  reach[3][2] (out): per axis the
-// interval a ray origin must lie in for the frames' margins to hold (the scene box grown by 1.5 extents) - the caller checks the
-// camera against it.  Returns false when a box is not finite.
-bool pt_bvh_quantize4(const std::vector<PtNode4>& nodes4, std::vector<PtNode4Q>* out, float reach[3][2]);

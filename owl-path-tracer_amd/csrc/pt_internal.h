@@ -36,8 +36,6 @@ struct pt_ctx {
     std::vector<PtNode4> nodes4; // two-level collapse of bvh.nodes for the wavefront kernel (pt_bvh_collapse4)
     int32_t root4 = -1;
     int depth4 = 0;
-    std::vector<PtNode4Q> nodes4q; // nodes4 as 64-byte records with 8-bit planes (pt_bvh_quantize4); empty if a box is not finite
-    float quant_reach[3][2] = {{0, 0}, {0, 0}, {0, 0}}; // where the camera may be for the records' margins to hold
     std::vector<PtNode8> nodes8; // three-level collapse for the group walk of sparse waves (pt_bvh_collapse8)
     int32_t root8 = -1;
     int depth8 = 0;
@@ -55,7 +53,7 @@ struct pt_ctx {
     bool have_scene = false;
 
     // device
-    DevBuf d_nodes8, d_nodes4q, d_nodes4, d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket, d_tiers, d_lobe;
+    DevBuf d_nodes8, d_nodes4, d_nodes, d_tris, d_shade, d_materials, d_texdesc, d_env, d_pixels, d_heads, d_rng, d_accum, d_out, d_out8, d_counters, d_dbg_in, d_dbg_out, d_slots, d_laps, d_ring, d_params, d_cost, d_sorted, d_sort_scratch, d_dbg_start, d_bucket, d_tiers, d_lobe;
     std::vector<void*> d_textures;
 
     // pixel queue
@@ -65,7 +63,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, coop = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, quant = 1, express_permille = -1, ns_express = 8, whole = -1, lobe_bins = 0;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, express_permille = -1, ns_express = 8, whole = -1, lobe_bins = 0;
     int tune[8] = {};
 
     void* comm = nullptr;   // ncclComm_t once pt_comm_init_rank / pt_group_create attached one (pt_comm.cpp)

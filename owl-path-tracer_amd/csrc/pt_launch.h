@@ -16,10 +16,12 @@ size_t pt_sort_scratch_bytes(uint32_t n);
 hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream);
 hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch,
                                  uint8_t* bucket, hipStream_t stream);
-hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int coop, int bins, int* block, size_t* lds_bytes, int* ns,
+hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int* block, size_t* lds_bytes, int* ns,
                               size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 int pt_debug_block(void);
-int pt_kernel_features(void);
+// pt_kernel_aux.hip: the lane-per-pixel variant (pt_launch_render / pt_kernel_geometry forward variant 1 to these)
+hipError_t pt_launch_render_lane(const PtKernelParams* p, int grid, size_t lds_bytes, hipStream_t stream, int count);
+hipError_t pt_lane_kernel_geometry(int count, int stack_entries, int* block, size_t* lds_bytes, int* ns, int* vgprs, int* max_blocks_per_cu);
 hipError_t pt_launch_store_params(const PtKernelParams* p, PtKernelParams* d_dst, hipStream_t stream);
 hipError_t pt_launch_pack_tri_ids(PtTri* tris, long long n, hipStream_t stream);
 hipError_t pt_launch_pack_rgba8(const float* rgb, uint32_t* out, long long n, hipStream_t stream);

@@ -30,26 +30,6 @@ struct PtNode4 {
 };
 static_assert(sizeof(PtNode4) == 128, "PtNode4 must be 128 bytes");
 
-// The quad node in 64 bytes (round 3, option "quant"): the same four boxes as 8-bit cell numbers in a frame of the node's own.
-// The vector L1 serves about one access per cycle and CU when every lane addresses its own line (profiles/r03_node_fetch.md), and
-// seven 16-byte loads of a 128-byte record are seven accesses; this record takes four, and half the L2 / fabric bytes.
-// Frame: per axis a cell size scale[a] (a power of two) and an origin (a multiple of it) one cell below the node's box;
-// plane = origin + q * scale, q in 0..254.  Lower planes are rounded down and upper planes up, each by one cell MORE than needed, so a
-// quantised box contains the float box it replaces with a margin of one cell: the slab test stays conservative with respect to
-// every hit the triangle test can report (the kernel tests in frame coordinates, node4_step<QUANT>, and its rounding
-// of the ray origin into the frame is worth less than half a cell because scale >= 2^-21 x the largest |o - origin| a ray can have)
-// and the image does not change - a few more boxes are entered (a first version on ONE global 16-bit grid entered too many: the
-// ground plane of C4 made the cells a tenth of a triangle wide and the triangle tests went up by 43 %).
-// q[plane][slot]: planes lo x, lo y, lo z, hi x, hi y, hi z.  child as in PtNode4 (-1: empty slot - the kernel masks it by the
-// reference, its planes are arbitrary).
-struct PtNode4Q {
-    float origin[3];
-    float scale[3];
-    uint8_t q[6][4];
-    int32_t child[4];
-};
-static_assert(sizeof(PtNode4Q) == 64, "PtNode4Q must be 64 bytes");
-
 // Three binary levels per record ("oct node", round 3): up to eight descendants of a binary node, each with its own box - the
 // record of the group walk (pt_kernel.hip, traverse_groups), where eight lanes test the eight children of ONE ray's node at once:
 // lane k of a group reads child k (2 x global_load_dwordx4; the eight lanes cover the record's two cache lines), so a ray goes down
@@ -174,11 +154,9 @@ struct PtKernelParams {
     int32_t n_full;            // chunks [0, n_full) have chunk_spp samples; the rest follow tail_len[] (shrinking chunks: short frame tail)
     int32_t tail_len[PT_MAX_TAIL_CHUNKS];
     const PtNode4* nodes4;     // wavefront kernel: quad nodes (null: walk PtNode[] one level per step); root / stack_entries then refer to them
-    const PtNode4Q* nodes4q;   // wavefront kernel: the quad nodes quantised to 64 bytes (null: walk nodes4)
     const PtNode8* nodes8;     // wavefront kernel: oct nodes of the group walk (null: no group walk)
     int32_t root8;             // root reference into nodes8 (leaf code if the scene is tiny)
     int32_t groups;            // group walk: 0 = never, 1 = when a wave has few rays to trace (sparse wave), 2 = always (tests)
-    int32_t coop;              // wavefront kernel, quad nodes: 1 = cooperative node fetch through an LDS staging area (node4_fetch_coop), 0 = per-lane loads
     int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
     const uint32_t* lobe_codes; // PT_LOBE_TABLE words: lobe thresholds per material (pt_lobe_code), index = material + 1
     int32_t lobe_bins;         // wavefront kernel: 1 = hit passes shade one predicted lobe at a time (pt_kernel.hip, LOBE-COHERENT HIT PASSES)
