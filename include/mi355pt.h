@@ -204,9 +204,9 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   level and running pixels up to which a wave counts as sparse);  "coop" / "quant": two validated experiments that are NOT in the product
  *   build (cooperative whole-line node fetch through an LDS staging area; 64-byte quad nodes with 8-bit planes) - builds made with
  *   EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1" contain them (default on there); elsewhere setting either to 1 returns PT_E_INVALID;
- *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" 0 (default) | 1 (a hit pass shades the hits of ONE predicted lobe at a
- *   time whenever the scene allows: < 2^23 triangles, < 32 materials) | -1 (the same when the materials can sample two or more lobes) - built and
- *   bit-exact, but it costs what it saves (profiles/r04_notes.md); "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
+ *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" 1 | -1: lobe-coherent hit passes (a hit pass shades the hits of ONE predicted
+ *   lobe at a time; -1: only when the materials can sample two or more lobes) - exists in `make lobebins` builds only (validated bit-exact, costs
+ *   what it saves: profiles/r04_notes.md); the product build returns PT_E_INVALID; "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
  *   the library does by itself when the 128-VGPR instance of a build needs scratch). */
 int pt_set_option(pt_ctx* ctx, const char* key, int64_t value);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);

@@ -1,6 +1,7 @@
 // pt_api.cpp -- implementation of the C-ABI declared in include/mi355pt.h (host side, HIP runtime).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -8,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pt_internal.h"
@@ -321,7 +323,10 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
-    else if (k == "lobe_bins") c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // hit passes by predicted lobe: 0 never (default), 1 whenever possible, -1 when the scene has two or more lobes
+    else if (k == "lobe_bins") {
+        if (value && !pt_kernel_lobe_bins()) return fail(c, PT_E_INVALID, "option 'lobe_bins': this build has no lobe bins (make -C owl-path-tracer_amd/csrc lobebins)");
+        c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value));
+    } // hit passes by predicted lobe: 0 never (default), 1 whenever possible, -1 when the scene has two or more lobes
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -367,7 +372,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     }
     if (n_tris > (size_t)(1u << 28)) return fail(c, PT_E_LIMIT, "too many triangles (%zu)", n_tris);
     std::vector<float> pos(n_tris * 9);
-    c->shade.assign(n_tris, PtShade{});
+    std::vector<size_t> mesh_first((size_t)n_meshes + 1, 0); // global id of a mesh's first triangle
     c->material_texture.assign((size_t)n_materials, -1);
     if (material_texture)
         for (int i = 0; i < n_materials; ++i) c->material_texture[i] = material_texture[i];
@@ -384,10 +389,9 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         // (the triangles of a large mesh are flattened by all build threads; bad: 1 = vertex index, 2 = normal, 3 = texcoord, + 4 * vertex)
         std::atomic<long long> bad{0};
         const size_t g0 = g;
+        mesh_first[(size_t)m] = g0;
         pt_parallel_ranges((size_t)ms.n_triangles, [&](size_t t_lo, size_t t_hi) {
             for (size_t t = t_lo; t < t_hi; ++t) {
-                PtShade& sh = c->shade[g0 + t];
-                sh.material = ms.material_index;
                 for (int k = 0; k < 3; ++k) {
                     const int32_t vi = ms.indices[t * 3 + (size_t)k];
                     if (vi < 0 || vi >= ms.n_vertices) { bad.store(1 + 4ll * vi); return; }
@@ -395,9 +399,6 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
                     if (!ms.normals || vi >= ms.n_normals) { bad.store(2 + 4ll * vi); return; }
                     if (textured && (!ms.texcoords || vi >= ms.n_texcoords)) { bad.store(3 + 4ll * vi); return; }
                     std::memcpy(&pos[(g0 + t) * 9 + (size_t)k * 3], ms.vertices + (size_t)vi * 3, 12);
-                    float* nd = k == 0 ? sh.n0 : (k == 1 ? sh.n1 : sh.n2);
-                    std::memcpy(nd, ms.normals + (size_t)vi * 3, 12);
-                    if (ms.texcoords && vi < ms.n_texcoords) std::memcpy(&sh.tc[k * 2], ms.texcoords + (size_t)vi * 2, 8);
                 }
             }
         });
@@ -409,6 +410,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
         }
         g += (size_t)ms.n_triangles;
     }
+    mesh_first[(size_t)n_meshes] = g;
 
     phase("flatten entities");
     // ---- BVH (replaces owlGroupBuildAccel, application.cpp:135-139) ----
@@ -493,26 +495,40 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     phase("BVH build");
     pt_bvh_layout(&c->bvh, c->node_pairs, c->leaf_align);
     c->stats.bvh_nodes = c->bvh.nodes.size();
-    pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
-    phase("quad nodes");
+    { // the two collapses only read the binary tree: side by side
+        std::thread oct([&] { pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8); });
+        pt_bvh_collapse4(c->bvh, &c->nodes4, &c->root4, &c->depth4);
+        oct.join();
+    }
     if (3 * c->depth4 + 1 > PT_MAX_STACK) c->nodes4.clear(); // the quad walk could need more stack than the kernel has: binary walk instead
-    pt_bvh_collapse8(c->bvh, c->wide_leaves, &c->nodes8, &c->root8, &c->depth8);
     if (7 * c->depth8 + 1 > PT_GROUP_STACK) c->nodes8.clear(); // a group's stack (eight LDS stack columns) could overflow: no group walk
-    phase("oct nodes");
-    { // shading records follow the triangles into leaf order (padding slots included); the triangle record carries the material index as well
+    phase("quad + oct nodes");
+    { // shading records in leaf order (padding slots included), gathered from the caller's arrays: the three vertex normals and
+      // texcoords of triangle `id` (device.cu:63-94) and its material, which the triangle record carries as well
         const size_t n_slots = c->bvh.tris.size();
-        std::vector<PtShade> by_leaf(n_slots);
+        c->shade.resize(n_slots);
         pt_parallel_ranges(n_slots, [&](size_t lo, size_t hi) {
+            int m = 0;
             for (size_t i = lo; i < hi; ++i) {
+                PtShade& sh = c->shade[i];
+                std::memset(&sh, 0, sizeof(sh));
                 const int32_t id = c->bvh.tris[i].id;
-                if (id == 0x7fffffff) { std::memset(&by_leaf[i], 0, sizeof(PtShade)); by_leaf[i].material = -1; continue; }
-                by_leaf[i] = c->shade[(size_t)id];
-                c->bvh.tris[i].material = by_leaf[i].material;
+                if (id == 0x7fffffff) { sh.material = -1; continue; }
+                if (!((size_t)id >= mesh_first[(size_t)m] && (size_t)id < mesh_first[(size_t)m + 1]))
+                    m = (int)(std::upper_bound(mesh_first.begin(), mesh_first.end(), (size_t)id) - mesh_first.begin()) - 1;
+                const pt_mesh& ms = meshes[m];
+                const size_t t = (size_t)id - mesh_first[(size_t)m];
+                sh.material = ms.material_index;
+                c->bvh.tris[i].material = ms.material_index;
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t vi = ms.indices[t * 3 + (size_t)k]; // validated above
+                    float* nd = k == 0 ? sh.n0 : (k == 1 ? sh.n1 : sh.n2);
+                    std::memcpy(nd, ms.normals + (size_t)vi * 3, 12);
+                    if (ms.texcoords && vi < ms.n_texcoords) std::memcpy(&sh.tc[k * 2], ms.texcoords + (size_t)vi * 2, 8);
+                }
             }
         });
-        c->shade.swap(by_leaf);
     }
-
     phase("shading records");
     // ---- textures, materials, environment ----
     c->textures.assign((size_t)n_textures, HostTexture{});
@@ -549,7 +565,7 @@ int upload_scene_to_device(pt_ctx* c)
     {   // the device copy of the triangle records carries the material with the id (PtTri::id): below 2^23 triangle slots a hit's
         // triangle slot leaves room for it in the word the kernel keeps per hit, and id << 8 stays a positive int (same tie-break order)
         // (packed on the device after the copy: pt_pack_tri_ids_kernel)
-        c->tri_packed = c->bvh.tris.size() < ((size_t)1 << 23);
+        c->tri_packed = pt_kernel_lobe_bins() && c->bvh.tris.size() < ((size_t)1 << 23); // (only builds with the lobe bins use it)
         if ((rc = upload(c, c->d_tris, c->bvh.tris.data(), c->bvh.tris.size() * sizeof(PtTri)))) return rc;
         if (c->tri_packed) HIP_TRY(c, pt_launch_pack_tri_ids((PtTri*)c->d_tris.p, (long long)c->bvh.tris.size(), c->stream));
     }

@@ -58,7 +58,8 @@
 #define PT_QUAD_REPS 1 // quad-node steps per burst (a quad step is two binary levels and up to three pushes)
 #endif
 #ifndef PT_WITH_LOBE_BINS
-#define PT_WITH_LOBE_BINS 1 // lobe-coherent hit passes (option "lobe_bins"; off by default at run time): 0 compiles them out (A/B of the code they add)
+#define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
+                            // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
 #ifndef PT_PURE_MIN
 #define PT_PURE_MIN 24     // lanes the fullest lobe bin must fill for a hit pass over that bin alone (option "tune4")
@@ -1271,3 +1272,5 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
     return e;
 }
 
+// does this build contain the lobe bins of the hit pass (option "lobe_bins")?
+extern "C" int pt_kernel_lobe_bins(void) { return PT_WITH_LOBE_BINS; }

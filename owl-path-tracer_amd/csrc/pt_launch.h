@@ -19,6 +19,7 @@ hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radi
 hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int* block, size_t* lds_bytes, int* ns,
                               size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 int pt_debug_block(void);
+int pt_kernel_lobe_bins(void);
 // pt_kernel_aux.hip: the lane-per-pixel variant (pt_launch_render / pt_kernel_geometry forward variant 1 to these)
 hipError_t pt_launch_render_lane(const PtKernelParams* p, int grid, size_t lds_bytes, hipStream_t stream, int count);
 hipError_t pt_lane_kernel_geometry(int count, int stack_entries, int* block, size_t* lds_bytes, int* ns, int* vgprs, int* max_blocks_per_cu);

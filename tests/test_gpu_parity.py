@@ -372,23 +372,6 @@ def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
     want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(**env), W, H, 24, 16, want_rgba8=True, want_counters=True)
     assert_bitwise(rgb, want, "material coverage")
     np.testing.assert_array_equal(rgba, want8)
-    # lobe-coherent hit passes (round 4, option "lobe_bins", off by default): this scene samples all four lobes; the image must not
-    # depend on the bins - on with every threshold for a pass over one bin alone (tune4: 1 = always .. 200 = never), counted build too
-    gpu.set_option("count", 1)
-    gpu.set_option("lobe_bins", 1)
-    gpu.render(cam, W, H, 24, 16)
-    lb = gpu.stats()["lobes"]
-    gpu.set_option("lobe_bins", 0)
-    gpu.set_option("count", 0)
-    assert all(lb[i] > 0 for i in range(5)) and lb[7] > 0, lb  # four lobes + emitter hits; some passes ran one bin alone
-    assert gpu.stats()["scatters"] == cnt["scatters"] and gpu.stats()["rays"] == cnt["rays"]
-    for bins, pure_min in ((-1, 0), (1, 1), (1, 8), (1, 40), (1, 200)):
-        gpu.set_option("lobe_bins", bins)
-        gpu.set_option("tune4", pure_min)
-        got, _ = gpu.render(cam, W, H, 24, 16)
-        gpu.set_option("lobe_bins", 0)
-        gpu.set_option("tune4", 0)
-        assert_bitwise(got, want, "lobe bins %d, pure_min %d" % (bins, pure_min))
     # environment map path (device.cu:23-39,138-139): same scene under a synthetic 8-bit lat-long map
     yy, xx = np.mgrid[0:16, 0:32]
     envmap = ((xx * 8) | ((yy * 16) << 8) | (((xx + yy) * 5) << 16) | (0xFF << 24)).astype(np.uint32)
@@ -841,6 +824,62 @@ print("FALLBACK_OK", st["vgprs"])
 """ % dict(root=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PT_LIB_PATH=lib), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_lobe_bins_build():
+    """Lobe-coherent hit passes (round 4; libmi355pt_lobebins.so - the product build leaves them out, profiles/r04_notes.md): hits are
+    binned by the lobe their next draw will pick and a pass shades one bin at a time.  The image must not depend on it: a scene that
+    samples all four lobes (the car.json materials on spheres, textured ground, emitter), bins on with every threshold for a pass over
+    one bin alone (tune4: 1 = always .. 200 = never), and automatic."""
+    import subprocess, sys
+    from conftest import ROOT
+
+    lib = os.path.join(ROOT, "owl-path-tracer_amd", "libmi355pt_lobebins.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmi355pt_lobebins.so not built (make -C owl-path-tracer_amd/csrc lobebins)")
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import ptamd; ptamd.load()
+from owl_path_tracer_amd.pyhost import binding as B, scene_io, procedural
+import oracle as orc
+assert B.LIB_PATH.endswith("libmi355pt_lobebins.so"), B.LIB_PATH
+_, car = scene_io.parse_scene(os.path.join(%(root)r, "assets", "car.json"))
+mats = [(n, m, "") for n, m, _ in car]
+meshes = []
+for i, (name, m, _) in enumerate(mats):
+    if name == "Ground":
+        meshes.append((name, procedural.quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), (0, 1, 0), uv=True)))
+    elif name == "Light":
+        meshes.append((name, procedural.quad((-2, 4, -2), (2, 4, -2), (2, 4, 2), (-2, 4, 2), (0, -1, 0))))
+    else:
+        a = 2 * np.pi * i / len(mats)
+        meshes.append((name, procedural.uv_sphere((2.2 * np.cos(a), 0.5, 2.2 * np.sin(a)), 0.5, nu=24, nv=12)))
+ents = scene_io.build_entities(meshes, mats)
+gi = [n for n, _, _ in mats].index("Ground")
+tex = scene_io.checker_texture(32, 32, 4)
+env = dict(use_auto=True, intensity=0.6)
+ctx = B.Context(0)
+ctx.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
+W, H = 96, 64
+cam = B.to_camera_data([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H)
+S = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
+want, _, cnt = S.render(orc.camera_from_array(cam.as_array()), orc.make_env(**env), W, H, 24, 16, want_counters=True)
+ctx.set_option("count", 1); ctx.set_option("lobe_bins", 1)
+ctx.render(cam, W, H, 24, 16)
+st = ctx.stats(); lb = st["lobes"]
+ctx.set_option("count", 0)
+assert all(lb[i] > 0 for i in range(5)) and lb[7] > 0, lb   # four lobes + emitter hits; some passes shaded one bin alone
+assert st["scatters"] == cnt["scatters"] and st["rays"] == cnt["rays"]
+for bins, pure_min in ((0, 0), (-1, 0), (1, 1), (1, 8), (1, 40), (1, 200)):
+    ctx.set_option("lobe_bins", bins); ctx.set_option("tune4", pure_min)
+    got, _ = ctx.render(cam, W, H, 24, 16)
+    bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, (bins, pure_min, bad)
+print("LOBE_BINS_OK")
+""" % dict(root=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PT_LIB_PATH=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LOBE_BINS_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_library_communicator_single_rank(gpu, cornell):
