@@ -76,10 +76,11 @@ namespace {
 // the nearest hit child and pushes the other hit children (in slot order; any visiting order gives the same closest hit).
 // The lane reads its own record with 7 x global_load_dwordx4 = 7 vL1D accesses per lane and step.  (Two validated experiments that did not
 // pay - whole-line cooperative fetches through an LDS staging area, 64-byte records with 8-bit planes - live in variants/.)
-template <int STRIDE, int LDS_ENTRIES>
+template <int STRIDE, int LDS_ENTRIES, bool CENSUS = false>
 __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest, int& cur, int& sp,
-                                           uint32_t* cull_census = nullptr)
+                                           uint32_t* n_nohit = nullptr, uint32_t* n_beyond = nullptr)
 {
+    bool crossed = false; // CENSUS: the ray crosses some slot's box when the bound of the best hit is ignored
     const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4);
     const f32x4 lx = ldg4(nodes4, nb), ly = ldg4(nodes4, nb + 16), lz = ldg4(nodes4, nb + 32);
     const f32x4 hx = ldg4(nodes4, nb + 48), hy = ldg4(nodes4, nb + 64), hz = ldg4(nodes4, nb + 80), cf = ldg4(nodes4, nb + 96);
@@ -102,10 +103,10 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
         tf = tf * pad;
         tn[2 * p] = ta; tn[2 * p + 1] = tb;
         hit[2 * p] = ta <= tf.x; hit[2 * p + 1] = tb <= tf.y;
-        if (cull_census) { // instrumented instance: would the slot be hit without the bound of the best hit so far?
+        if (CENSUS) { // instrumented instance: would the slot be hit without the bound of the best hit so far?
             const float fa = fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmax_hw(t0z.x, t1z.x)) * 1.0000004f;
             const float fb = fmin_hw(fmin_hw(fmax_hw(t0x.y, t1x.y), fmax_hw(t0y.y, t1y.y)), fmax_hw(t0z.y, t1z.y)) * 1.0000004f;
-            cull_census[2] |= (ta <= fa ? 1u : 0u) | (tb <= fb ? 1u : 0u);
+            crossed = crossed || ta <= fa || tb <= fb;
         }
     }
     const int r0 = __float_as_int(cf.x), r1 = __float_as_int(cf.y), r2 = __float_as_int(cf.z), r3 = __float_as_int(cf.w);
@@ -117,10 +118,9 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     const bool in_b = m23 < m01; // the nearest hit is in slot pair {2, 3}
     const int nearc = in_b ? r23 : r01;
     const bool any = hit[0] || hit[1] || hit[2] || hit[3];
-    if (cull_census) { // [0] steps that enter nothing, [1] ... although the ray crosses one of the boxes: the node lies beyond the best hit
-        cull_census[0] += any ? 0u : 1u;
-        cull_census[1] += (!any && cull_census[2]) ? 1u : 0u;
-        cull_census[2] = 0u;
+    if (CENSUS) { // steps that enter nothing, and of those the ones where the ray does cross a box: the node lies beyond the best hit
+        *n_nohit += any ? 0u : 1u;
+        *n_beyond += (!any && crossed) ? 1u : 0u;
     }
     // push order: the two slots of the OTHER pair first, the nearest's sibling last (popped first): siblings share a parent box, so
     // the sibling is usually the next nearest.  Three pushes at most.
@@ -520,7 +520,10 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         if (IS_MISS) { w.miss_head = w.wrap(q_head + n); w.miss_count = q_count - n; } else { w.hit_head = w.wrap(q_head + n); w.hit_count = q_count - n; }
     }
     const bool mine = lane < n;
-    if (COUNT) { cn.sched[IS_MISS ? 8 : 6] += 1; cn.sched[IS_MISS ? 9 : 7] += n; }
+    if (COUNT) { // (all four with constant indices and selected values: a dynamic index sends the counter block to scratch)
+        const uint32_t m1 = IS_MISS ? 1u : 0u, mn = IS_MISS ? (uint32_t)n : 0u;
+        cn.sched[6] += 1u - m1; cn.sched[7] += (uint32_t)n - mn; cn.sched[8] += m1; cn.sched[9] += mn;
+    }
     bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
     int branch = -1; // COUNT: which branch of the hit shader the item took (0..3 sampled lobe, 4 emitter, 5 NaN retry)
     if (mine) {
@@ -998,7 +1001,9 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
         if (COUNT && w.n_dead > 0 && t_dead == 0) {
             t_dead = t0;
             if (P.census_mode == 1) { // census of the wind-down only
+#pragma unroll
                 for (int k = 0; k < 7; ++k) cn.cyc[k] = 0;
+#pragma unroll
                 for (int k = 0; k < 19; ++k) cn.sched[k] = 0;
                 cn.nodes = cn.tris = cn.rays = 0;
             }
@@ -1016,7 +1021,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
             shade_pass<COUNT>(P, w, lane, cn, miss_pass);
             if (!miss_pass || !w.miss_blocked) n_rounds = 0; // hits are always running paths; a miss pass may have done nothing but poll unpublished tickets
             w.retune(mb0, rl0, fb0);
-            if (COUNT) cn.cyc[miss_pass ? 4 : 3] += __builtin_amdgcn_s_memtime() - t0;
+            if (COUNT) { const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0; cn.cyc[3] += miss_pass ? 0ull : dt; cn.cyc[4] += miss_pass ? dt : 0ull; }
         } else if (starving) {
             // every live slot of this wave waits for a work item that another wave is still rendering
             __builtin_amdgcn_s_sleep(64);
@@ -1150,7 +1155,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                             if (rep >= n_reps) break;
                             if (cur >= 0) {
                                 if (COUNT) cn.nodes += nodes4 ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
-                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff>(nodes4, stack, ovf, o, inv, h.t, cur, sp, COUNT ? cn.cull : nullptr);
+                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, COUNT>(nodes4, stack, ovf, o, inv, h.t, cur, sp, &cn.cull_nohit, &cn.cull_beyond);
                                 else if (COUNT) node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth); // the one-level walk exists in the instrumented instance only
                                 PT_STASH_LEAF(0x7fffffff);
                             }
@@ -1181,7 +1186,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                         if (COUNT) cn.tris += (uint32_t)count;
                         const float t_before = h.t;
                         leaf_test(tris, firstt, count, o, d, h);
-                        if (COUNT) cn.cull[3] += h.t == t_before ? 1u : 0u;
+                        if (COUNT) cn.leaf_noimp += h.t == t_before ? 1u : 0u;
                         if (cur < PT_DONE) { // the lane was blocked on a second leaf: it becomes the pending one
                             pend = cur;
                             if (sp > 0) {

@@ -30,7 +30,7 @@ struct Counters {
     uint32_t grp[6] = {};    // wave-uniform census of the group walk: phases, iterations, busy groups, node groups, leaf groups, rays
     unsigned long long grp_cyc = 0;
     uint32_t lobe[16] = {};  // wave-uniform census of the hit passes by sampled lobe (PtCounters::lobes)
-    uint32_t cull[4] = {};   // per lane: quad steps that enter no child, of those: node beyond the best hit; [2] scratch; [3] leaf steps that do not improve the hit
+    uint32_t cull_nohit = 0, cull_beyond = 0, leaf_noimp = 0; // per lane: quad steps that enter no child; of those: node beyond the best hit; leaf steps that do not improve the hit
 };
 
 // Pointers read out of the parameter block are generic; every buffer is hipMalloc memory, so all accesses below go through
@@ -363,11 +363,12 @@ __device__ __forceinline__ void flush_counters(const PtKernelParams& P, const Co
 #pragma unroll
         for (int k = 0; k < 16; ++k) atomicAdd(&P.counters->lobes[k], (unsigned long long)cn.lobe[k]);
     }
-    for (int k = 0; k < 4; ++k) {
-        unsigned long long x = k == 2 ? 0ull : cn.cull[k];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters->trav[k], x);
+    {
+        unsigned long long x0 = cn.cull_nohit, x1 = cn.cull_beyond, x3 = cn.leaf_noimp;
+        for (int off = 32; off > 0; off >>= 1) { x0 += __shfl_down(x0, off, 64); x1 += __shfl_down(x1, off, 64); x3 += __shfl_down(x3, off, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&P.counters->trav[0], x0); atomicAdd(&P.counters->trav[1], x1); atomicAdd(&P.counters->trav[3], x3); }
     }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         unsigned long long x = cn.depth[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);

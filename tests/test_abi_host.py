@@ -2,12 +2,15 @@
 include/mi355pt.h, the host BVH builder agrees with brute force, the camera and pixel-shard helpers are right,
 and the render path refuses to run without the GPU (no fallback)."""
 import ctypes as C
+import os
 import re
 
 import numpy as np
 import pytest
 
 from owl_path_tracer_amd.pyhost import binding as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
@@ -265,3 +268,24 @@ def test_tier_plan_on_the_host():
     t = np.zeros(257, np.uint32)
     assert B.lib().pt_debug_plan_tiers(one.ctypes.data_as(C.POINTER(C.c_uint32)), 0, 96, 0, t.ctypes.data_as(C.POINTER(C.c_uint32)), 257) < 0
     assert B.lib().pt_debug_plan_tiers(one.ctypes.data_as(C.POINTER(C.c_uint32)), 4096, 96, 0, t.ctypes.data_as(C.POINTER(C.c_uint32)), 16) < 0
+
+
+def test_render_kernel_instances_need_no_scratch():
+    """pt_render refuses an instance of the wavefront kernel that spills to scratch (such builds rendered wrong pixels in round 1), so a
+    source change that pushes the instrumented instance into scratch breaks every counted render and every scene without quad nodes -
+    on the GPU box only.  hipcc reports the resource usage without a GPU: all three instances of both builds must show ScratchSize 0
+    (found the hard way in round 4: a dynamic index into the counter block sent all of it to scratch)."""
+    import re, shutil, subprocess, tempfile
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "owl-path-tracer_amd", "csrc")
+    for extra in ([], ["-DPT_WITH_LOBE_BINS=1"]):
+        with tempfile.TemporaryDirectory() as td:
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only", "-o", os.path.join(td, "k.s"),
+                                os.path.join(csrc, "pt_kernel.hip"), "-Rpass-analysis=kernel-resource-usage"] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        blocks = re.findall(r"Function Name: (\S*pt_render_wave_kernel\S*).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
+        assert len(blocks) == 3, blocks
+        assert all(int(sz) == 0 for _, sz in blocks), (extra, blocks)

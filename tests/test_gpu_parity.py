@@ -42,13 +42,25 @@ def _upload(ctx, sc, textures=None, mesh_textures=None, env=None):
     ctx.upload_scene(sc["entities"], _mats(sc), textures=textures, mesh_textures=mesh_textures, env=env)
 
 
+# The oracle gets ITS OWN camera (camera.cpp:3-21 restated in oracle/pt_oracle.c) from the look-at parameters, not the 48 bytes the product's
+# pt_to_camera_data computed: a deviation in either shows as a parity failure instead of cancelling out (round-3 verdict, weak #2).
+_CAM_ARGS = {}
+
+
+def mkcam(look_from, look_at, look_up, vfov, W, H):
+    cam = B.to_camera_data(look_from, look_at, look_up, vfov, W, H)
+    _CAM_ARGS[cam.as_array().tobytes()] = (tuple(look_from), tuple(look_at), tuple(look_up), float(vfov), int(W), int(H))
+    return cam
+
+
 def _cam(sc, W, H):
     c = sc["camera"]
-    return B.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
+    return mkcam(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H)
 
 
 def _ocam(orc, cam):
-    return orc.camera_from_array(cam.as_array())
+    args = _CAM_ARGS[cam.as_array().tobytes()]  # KeyError: build the camera with mkcam()
+    return orc.to_camera_data(*args)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -366,7 +378,7 @@ def test_material_coverage_image_bitwise(gpu, orc, scene_io, procedural):
     env = dict(use_auto=True, intensity=0.6)
     gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
     W, H = 96, 64
-    cam = B.to_camera_data([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H)
+    cam = mkcam([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H)
     rgb, rgba = gpu.render(cam, W, H, 24, 16, want_rgba8=True)
     S = orc.Scene(flat)
     want, want8, cnt = S.render(_ocam(orc, cam), orc.make_env(**env), W, H, 24, 16, want_rgba8=True, want_counters=True)
@@ -521,7 +533,7 @@ def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
 
 def test_error_paths(gpu):
     fresh = B.Context(0)
-    cam = B.to_camera_data([0, 0, 3], [0, 0, 0], [0, 1, 0], 40, 8, 8)
+    cam = mkcam([0, 0, 3], [0, 0, 0], [0, 1, 0], 40, 8, 8)
     with pytest.raises(B.PtError, match="no geometries"):
         fresh.render(cam, 8, 8, 1, 1)
     # empty scene renders the environment only
@@ -581,7 +593,7 @@ def test_c4_dragon_standin_full_size(gpu, orc, scene_io, procedural):
     env = dict(color=(1, 1, 1), intensity=0.0)
     gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
     W, H = 1920, 1080
-    cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    cam = mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
     a, _ = gpu.render(cam, W, H, 1024, 16)
     st = gpu.stats()
     assert np.isfinite(a).all()
@@ -630,7 +642,7 @@ def test_c3_mitsuba_standin_full_size(gpu, orc, scene_io, procedural):
     env = dict(use_auto=True, intensity=1.0)
     gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
     W = H = 1024
-    cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    cam = mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
     a, _ = gpu.render(cam, W, H, 512, 16)
     st = gpu.stats()
     S = orc.Scene(scene_io.flatten_scene(ents, mats))
@@ -638,6 +650,40 @@ def test_c3_mitsuba_standin_full_size(gpu, orc, scene_io, procedural):
     _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 8, 16, "C3")
     assert a.mean() > 0.05
     print("C3 kernel_ms=%.1f Msamples/s=%.1f" % (st["kernel_ms"], W * H * 512 / st["kernel_ms"] / 1e3))
+
+
+def test_c3_material_sweep_full_size(gpu, orc, scene_io, procedural):
+    """The material sweep SURVEY 8(d) asks of C3 ("for BSDF coverage add a material sweep over metallic/clearcoat/transmission/sheen"; the
+    reference's driver is test_loop / modify_sbt, application.hpp:89-108, application.cpp:329-360) at FULL size: 1024x1024, 512 spp, depth
+    16 - the attribute is set on 'outside' and 'inside' through pt_set_materials (no BVH rebuild), a random pixel subset is compared
+    with the oracle at full spp and, for the four-lobe variant, every pixel of the frame at 4 spp."""
+    _, mats = scene_io.parse_scene(os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets", "mitsuba.json"))
+    ents = scene_io.build_entities(procedural.mitsuba_standin(), mats)
+    env = dict(use_auto=True, intensity=1.0)
+    base = np.stack([m for _, m, _ in mats]).astype(np.float32)
+    names = [n for n, _, _ in mats]
+    gpu.upload_scene(ents, base, env=B.make_env(**env))
+    W = H = 1024
+    cam = mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+    S = orc.Scene(scene_io.flatten_scene(ents, mats))
+    # material_data field indices (device_global.hpp:19-36): 4 metallic, 7 roughness, 9 sheen, 11 clearcoat, 14 transmission, 15 its roughness
+    sweep = [("metallic 1, roughness .3", {4: 1.0, 7: 0.3}), ("clearcoat 1", {11: 1.0}), ("transmission .5, roughness .3", {14: 0.5, 15: 0.3}), ("sheen 1", {9: 1.0}),
+             ("four lobes: metallic .3, clearcoat 1, transmission .5, sheen .5", {4: 0.3, 11: 1.0, 14: 0.5, 9: 0.5})]
+    for k, (label, edits) in enumerate(sweep):
+        mm = base.copy()
+        for i, n in enumerate(names):
+            if n != "ground":
+                for f, v in edits.items():
+                    mm[i, f] = v
+        gpu.set_materials(mm)
+        S.set_materials(mm)
+        a, _ = gpu.render(cam, W, H, 512, 16)
+        st = gpu.stats()
+        assert np.isfinite(a).all(), label
+        _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 512, 16, 300, 40 + k)
+        if k == len(sweep) - 1:
+            _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C3 " + label)
+        print("C3 sweep %-62s kernel_ms=%.1f Msamples/s=%.1f" % (label, st["kernel_ms"], W * H * 512 / st["kernel_ms"] / 1e3))
 
 
 def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
@@ -653,7 +699,7 @@ def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
     gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
     assert gpu.stats()["n_triangles"] > 1_500_000
     W, H = 1920, 1080
-    cam = B.to_camera_data([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, W, H)
+    cam = mkcam([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, W, H)
     gpu.set_option("count", 1)
     a, _ = gpu.render(cam, W, H, 4096, 16)
     st = gpu.stats()
@@ -677,7 +723,7 @@ def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
     gpu.upload_scene(ents, mat, env=env)
     assert gpu.stats()["bvh_nodes"] == 0
     W, H = 96, 64
-    cam = B.to_camera_data([0, 1.5, 3], [0, 0, 0], [0, 1, 0], 45, W, H)
+    cam = mkcam([0, 1.5, 3], [0, 0, 0], [0, 1, 0], 45, W, H)
     S = orc.Scene(scene_io.flatten_scene(ents, [("quad", mat[0], "")]))
     want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 8)
     for k in (2, 1):
@@ -724,7 +770,7 @@ def test_group_walk_bitwise(gpu, orc, cornell, scene_io, procedural):
         ents = scene_io.build_entities(procedural.dragon_standin(), mats)
         gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
         W, H = 1920, 1080
-        cam = B.to_camera_data([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
+        cam = mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, W, H)
         imgs = {}
         for g in (2, 1, 0):
             gpu.set_option("groups", g)
@@ -818,7 +864,7 @@ got, _ = ctx.render(cam, W, H, 16, 4)
 st = ctx.stats()
 assert st["kernel_variant"] == 3 and 128 < st["vgprs"] <= 168, (st["kernel_variant"], st["vgprs"])
 flat = scene_io.flatten_scene(sc["entities"], sc["materials"], {0: tex})
-want, _, _ = orc.Scene(flat).render(orc.camera_from_array(cam.as_array()), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 4)
+want, _, _ = orc.Scene(flat).render(orc.to_camera_data(c["look_from"], c["look_at"], c["look_up"], c["vertical_fov"], W, H), orc.make_env(use_auto=True, intensity=1.0), W, H, 16, 4)
 assert (got.view(np.uint32) == want.view(np.uint32)).all(), int((got.view(np.uint32) != want.view(np.uint32)).sum())
 print("FALLBACK_OK", st["vgprs"])
 """ % dict(root=ROOT)
@@ -864,7 +910,7 @@ ctx.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0
 W, H = 96, 64
 cam = B.to_camera_data([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H)
 S = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
-want, _, cnt = S.render(orc.camera_from_array(cam.as_array()), orc.make_env(**env), W, H, 24, 16, want_counters=True)
+want, _, cnt = S.render(orc.to_camera_data([0, 3.5, 6.5], [0, 0.4, 0], [0, 1, 0], 45, W, H), orc.make_env(**env), W, H, 24, 16, want_counters=True)
 ctx.set_option("count", 1); ctx.set_option("lobe_bins", 1)
 ctx.render(cam, W, H, 24, 16)
 st = ctx.stats(); lb = st["lobes"]
@@ -913,7 +959,7 @@ def test_furnace_against_reference_rendered_images_gpu(gpu, orc, scene_io, proce
 
     ents, mats = F.setup(scene_io, procedural, key)
     gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(color=(1, 1, 1), intensity=1.0))
-    cam = B.to_camera_data([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, F.W, F.H)
+    cam = mkcam([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, F.W, F.H)
     rgb, rgba = gpu.render(cam, F.W, F.H, F.SPP, F.DEPTH, want_rgba8=True)
     F.check(key, rgba)
     S = orc.Scene(scene_io.flatten_scene(ents, mats))
