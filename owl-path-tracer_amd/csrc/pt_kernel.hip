@@ -61,6 +61,9 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
+#ifndef PT_TOPUP_MIN
+#define PT_TOPUP_MIN 0 // > 0: a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"); 0 = never
+#endif
 #ifndef PT_PURE_MIN
 #define PT_PURE_MIN 24     // lanes the fullest lobe bin must fill for a hit pass over that bin alone (option "tune4")
 #endif
@@ -442,7 +445,8 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
 #define LFF(f, s) __uint_as_float(lray[(f) * ns + (s)])
 #define GF(f, s) gstate[(f) * ns + (s)]
 #define GFF(f, s) __uint_as_float(gstate[(f) * ns + (s)])
-    int n;
+    int n, n1 = 0, n2 = 0; // items of the pass: n1 from the queue it was called for, n2 topped up from the other one
+    bool lane_miss = IS_MISS;
     int ps_slot = 0;
     if (PT_WITH_LOBE_BINS && !IS_MISS && P.lobe_bins) {
         // ---- LOBE-COHERENT HIT PASSES (round 4) ----------------------------------------------------------------------------------
@@ -499,7 +503,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             t2 = t2 < room ? t2 : room; room -= t2;
             t3 = t3 < room ? t3 : room;
         }
-        n = t0 + t1 + t2 + t3;
+        n = n1 = t0 + t1 + t2 + t3;
         if (lane < n) {
             const int b = lane < t0 ? 0 : (lane < t0 + t1 ? 1 : (lane < t0 + t1 + t2 ? 2 : 3));
             const int i = lane - (b > 0 ? t0 : 0) - (b > 1 ? t1 : 0) - (b > 2 ? t2 : 0);
@@ -512,17 +516,27 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         w.binned -= n;
         if (COUNT) cn.lobe[7] += pure;
     } else {
+        // the queue the pass was called for, topped up from the other one when that holds at least topup_min entries: the second half of
+        // a pass (sample accumulation, next camera ray / work item, state write-back) is the same for both kinds and costs as much
+        // as the hit shader itself, so lanes a half-empty batch leaves idle may as well serve the other queue (option "tune0")
         uint8_t* q = IS_MISS ? w.missq : w.hitq;
-        const int q_head = IS_MISS ? w.miss_head : w.hit_head;
-        const int q_count = IS_MISS ? w.miss_count : w.hit_count;
-        n = q_count < PT_WAVE ? q_count : PT_WAVE;
-        if (lane < n) ps_slot = (int)q[w.wrap(q_head + lane)];
-        if (IS_MISS) { w.miss_head = w.wrap(q_head + n); w.miss_count = q_count - n; } else { w.hit_head = w.wrap(q_head + n); w.hit_count = q_count - n; }
+        uint8_t* q2 = IS_MISS ? w.hitq : w.missq;
+        const int q_head = IS_MISS ? w.miss_head : w.hit_head, q2_head = IS_MISS ? w.hit_head : w.miss_head;
+        const int q_count = IS_MISS ? w.miss_count : w.hit_count, q2_count = IS_MISS ? w.hit_count : w.miss_count;
+        n1 = q_count < PT_WAVE ? q_count : PT_WAVE;
+        const int topup_min = P.tune[0] > 0 ? P.tune[0] : PT_TOPUP_MIN;
+        if (topup_min > 0 && topup_min <= PT_WAVE && q2_count >= topup_min && (IS_MISS || !w.miss_blocked)) n2 = q2_count < PT_WAVE - n1 ? q2_count : PT_WAVE - n1;
+        n = n1 + n2;
+        if (lane < n1) ps_slot = (int)q[w.wrap(q_head + lane)];
+        else if (lane < n) { ps_slot = (int)q2[w.wrap(q2_head + lane - n1)]; lane_miss = !IS_MISS; }
+        const int hit_taken = IS_MISS ? n2 : n1, miss_taken = IS_MISS ? n1 : n2;
+        w.hit_head = w.wrap(w.hit_head + hit_taken); w.hit_count -= hit_taken;
+        w.miss_head = w.wrap(w.miss_head + miss_taken); w.miss_count -= miss_taken;
     }
     const bool mine = lane < n;
     if (COUNT) { // (all four with constant indices and selected values: a dynamic index sends the counter block to scratch)
-        const uint32_t m1 = IS_MISS ? 1u : 0u, mn = IS_MISS ? (uint32_t)n : 0u;
-        cn.sched[6] += 1u - m1; cn.sched[7] += (uint32_t)n - mn; cn.sched[8] += m1; cn.sched[9] += mn;
+        const uint32_t m1 = IS_MISS ? 1u : 0u, nm = (uint32_t)(IS_MISS ? n1 : n2);
+        cn.sched[6] += 1u - m1; cn.sched[7] += (uint32_t)n - nm; cn.sched[8] += m1; cn.sched[9] += nm;
     }
     bool to_ray = false, to_hit = false, to_wait = false, died = false, started = false, ended = false;
     int branch = -1; // COUNT: which branch of the hit shader the item took (0..3 sampled lobe, 4 emitter, 5 NaN retry)
@@ -554,10 +568,10 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             if (COUNT) ++cn.rays;
             if (P.dbg_start && !P.cost_out) atomicAdd(P.dbg_start + (size_t)P.width * (size_t)P.height + (uint32_t)px + (uint32_t)P.width * (uint32_t)py, 1u); // diagnostics: rays per pixel
             v3 radiance;
-            const int tslot = IS_MISS ? -1 : (int)(LF(L_AZ, ps_slot) & (PT_WITH_LOBE_BINS ? P.hit_slot_mask : 0xffffffffu)); // (the hit's material rides in the top byte: retire)
+            const int tslot = lane_miss ? -1 : (int)(LF(L_AZ, ps_slot) & (PT_WITH_LOBE_BINS ? P.hit_slot_mask : 0xffffffffu)); // (the hit's material rides in the top byte: retire)
             const uint32_t scat0 = cn.scat;
             int r = shade_hit<COUNT>(P, P.materials, tslot, LFF(L_AX, ps_slot), LFF(L_AY, ps_slot), ps, radiance, cn);
-            if (COUNT && !IS_MISS) branch = r == SR_RETRY ? 5 : (cn.scat != scat0 ? ps.lobe : 4);
+            if (COUNT && !lane_miss) branch = r == SR_RETRY ? 5 : (cn.scat != scat0 ? ps.lobe : 4);
             if (r == SR_RETRY) {
                 to_hit = true; // same hit, fresh draws (device.cu:196-201); L_A* still hold the hit
             } else if (r == SR_END) {
@@ -624,7 +638,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
             }
         }
     }
-    if (COUNT && !IS_MISS) {
+    if (COUNT && (!IS_MISS || n2 > 0)) {
         int bodies = 0, branches = 0;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -648,7 +662,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
     w.n_run += popc64(__ballot(started)) - popc64(__ballot(ended));
     if (COUNT) { cn.sched[16] += popc64(m_wait); cn.sched[17] += (w.n_dead > 0) ? n : 0; } // [17]: rays shaded after the queue ran dry (wind-down)
     // a pass that only polled unpublished tickets must not be repeated before the wave has done something else
-    w.miss_blocked = IS_MISS && n > 0 && popc64(m_wait) == n;
+    w.miss_blocked = n > 0 && popc64(m_wait) == n; // (only entries of the miss queue can be slots that wait for a ticket)
 #undef LF
 #undef LFF
 #undef GF

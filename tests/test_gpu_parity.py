@@ -438,6 +438,12 @@ def test_chunked_sharded_and_material_sweep(gpu, orc, cornell):
             gpu.set_option(k, v)
         want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, spp, 16)
         assert_bitwise(got, want, "schedule %r at %d spp" % (opts, spp))
+    # topped-up shading passes (option "tune0": a pass with idle lanes also takes entries of the other queue from this many on)
+    for k in (1, 8, 24, 64):
+        gpu.set_option("tune0", k)
+        got, _ = gpu.render(cam, W, H, 70, 16)
+        gpu.set_option("tune0", 0)
+        assert_bitwise(got, by_cost, "topped-up shading passes, threshold %d" % k)
     # pixel-tile shards are disjoint: the sum over ranks (what the RCCL reduce computes) is the 1-GPU image bit-for-bit
     acc = np.zeros_like(full)
     for r in range(3):
