@@ -61,8 +61,16 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
+#ifndef PT_COMBINED_TRIGGER
+#define PT_COMBINED_TRIGGER 0 // (A/B) > 0: a shading pass is due as soon as the hit and the miss queue hold a full batch TOGETHER, each at least this many
+#endif
+#ifndef PT_PUSH_SORTED
+#define PT_PUSH_SORTED 0 // quad step: 1 = the three children that are not entered go on the stack strictly by entry distance (A/B)
+#endif
 #ifndef PT_TOPUP_MIN
-#define PT_TOPUP_MIN 0 // > 0: a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"); 0 = never
+#define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
+                       // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
+                       // miss shader (atan2, asin, a texel) is too long to run for a few topped-up lanes (C5: 3 194 -> 3 219)
 #endif
 #ifndef PT_PURE_MIN
 #define PT_PURE_MIN 24     // lanes the fullest lobe bin must fill for a hit pass over that bin alone (option "tune4")
@@ -131,11 +139,21 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     const bool swap_o = in_b ? b01 : b23; // the other pair's second slot is the nearer one: push it second
     const int oa = in_b ? r0 : r2, ob = in_b ? r1 : r3;
     const bool ha = in_b ? hit[0] : hit[2], hb = in_b ? hit[1] : hit[3];
-    const int x1 = swap_o ? oa : ob, x2 = swap_o ? ob : oa;
-    const bool h1 = swap_o ? ha : hb, h2 = swap_o ? hb : ha;
+    int x1 = swap_o ? oa : ob, x2 = swap_o ? ob : oa;
+    bool h1 = swap_o ? ha : hb, h2 = swap_o ? hb : ha;
     const bool first_of_pair = in_b ? !b23 : !b01; // the nearest is the first slot of its pair
-    const int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
-    const bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
+    int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
+    bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
+#if PT_PUSH_SORTED
+    {   // all three by distance, farthest first: the partner goes where its entry distance puts it instead of always last
+        const float ko_far = in_b ? (b01 ? k0 : k1) : (b23 ? k2 : k3), ko_near = in_b ? m01 : m23; // the other pair's keys
+        const float kp = in_b ? (first_of_pair ? k3 : k2) : (first_of_pair ? k1 : k0);               // the partner's key
+        const bool p_first = kp > ko_far, p_mid = !p_first && kp > ko_near;
+        const int y1 = p_first ? x3 : x1, y2 = p_first ? x1 : (p_mid ? x3 : x2), y3 = (p_first || p_mid) ? x2 : x3;
+        const bool g1 = p_first ? h3 : h1, g2 = p_first ? h1 : (p_mid ? h3 : h2), g3 = (p_first || p_mid) ? h2 : h3;
+        x1 = y1; x2 = y2; x3 = y3; h1 = g1; h2 = g2; h3 = g3;
+    }
+#endif
     if (LDS_ENTRIES == 0x7fffffff) {
         // common instance (the caller made sure sp + 3 stays inside the LDS part): store above the top whether or not the entry is
         // pushed - the slot is free either way - and advance sp by the predicate; no branches
@@ -379,6 +397,8 @@ struct WaveCtx {
     bool miss_blocked; // the last miss pass only polled tickets whose predecessor chunk is still running
     int ray_low, min_batch, full_batch; // shading-batch thresholds (PT_RAY_LOW, PT_MIN_BATCH, 64; pt_set_option "tune1".."tune3")
     WaveTier tier;  // take_ticket
+    int topup_min;  // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (0 or > 64: never)
+    bool topup;     // ... at all
     int n_run;      // slots of this wave with a (pixel, chunk) running
     int adapt;      // 1: the thresholds follow n_run: a wave with few running pixels shades small batches instead of waiting for its slowest ray, and
                     // keeps stepping nodes while half of the lanes that started a burst still want to (1/8 shard of C4 391 -> 350 ms, 1/64 251 -> 214 ms)
@@ -417,6 +437,10 @@ __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
     const int hits = w.hit_count + w.binned; // hits waiting for shading: not yet classified + in the lobe bins
     if (hits >= w.full_batch) return PICK_HIT;
     if (miss_ok && w.miss_count >= w.full_batch) return PICK_MISS;
+#if PT_COMBINED_TRIGGER
+    // (A/B) with topped-up passes a full batch can be made of both queues: go as soon as they hold one together
+    if (w.topup && miss_ok && hits + w.miss_count >= w.full_batch && hits >= PT_COMBINED_TRIGGER && w.miss_count >= PT_COMBINED_TRIGGER) return hits >= w.miss_count ? PICK_HIT : PICK_MISS;
+#endif
     if (w.ray_count < w.ray_low) {
         // the ray queue is about to run dry: a half-full shading pass is cheaper than idle traversal lanes (traversal is ~80 %
         // of a wave's time, shading ~12 %)
@@ -524,7 +548,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         const int q_head = IS_MISS ? w.miss_head : w.hit_head, q2_head = IS_MISS ? w.hit_head : w.miss_head;
         const int q_count = IS_MISS ? w.miss_count : w.hit_count, q2_count = IS_MISS ? w.hit_count : w.miss_count;
         n1 = q_count < PT_WAVE ? q_count : PT_WAVE;
-        const int topup_min = P.tune[0] > 0 ? P.tune[0] : PT_TOPUP_MIN;
+        const int topup_min = w.topup_min;
         if (topup_min > 0 && topup_min <= PT_WAVE && q2_count >= topup_min && (IS_MISS || !w.miss_blocked)) n2 = q2_count < PT_WAVE - n1 ? q2_count : PT_WAVE - n1;
         n = n1 + n2;
         if (lane < n1) ps_slot = (int)q[w.wrap(q_head + lane)];
@@ -994,6 +1018,8 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     }
     if (w.tier.express) __builtin_amdgcn_s_setprio(3);
     w.miss_blocked = false;
+    w.topup_min = P.tune[0] > 0 ? P.tune[0] : ((P.env_use_map && P.env_map.width > 0) ? 0 : PT_TOPUP_MIN);
+    w.topup = w.topup_min > 0 && w.topup_min <= PT_WAVE;
     w.min_batch = P.tune[1] > 0 ? P.tune[1] : PT_MIN_BATCH;
     w.ray_low = P.tune[2] > 0 ? P.tune[2] : PT_RAY_LOW;
     w.full_batch = P.tune[3] > 0 ? P.tune[3] : PT_WAVE;
