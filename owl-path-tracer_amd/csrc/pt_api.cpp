@@ -722,7 +722,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     const int group_entries = P.nodes8 ? 7 * c->depth8 + 1 : 0;
     size_t lds = 0, state_words = 0;
     int vg = 0, sg = 0, slds = 0, occ = 0, block = 0, ns = 0;
-    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : 96; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
+    static const int default_ns = [] { const char* e = getenv("PT_DEFAULT_NS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 252 ? v : 96; }(); // (A/B builds of tools/)
+    int want_ns = c->slots_per_wave > 0 ? c->slots_per_wave : default_ns; // 16 waves/CU up to 104; 64..255 swept on C4 (profiles/r01_summary.md), 88..104 within 1 %
     // variant of the launch: the wavefront kernel's product instance (2) unless it needs scratch in this build - then its fallback
     // instance with the larger register budget (3): slower (12 instead of 16 waves per CU), the same arithmetic
     // (the one-level walk over PtNode[] - option quad = 0, or a tree too deep for the quad walk's stack bound - is compiled into the
@@ -772,7 +773,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             }
         }
         if (!tiers) {
-            want_ns = 96;
+            want_ns = default_ns;
             HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }

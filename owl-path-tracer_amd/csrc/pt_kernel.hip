@@ -61,12 +61,6 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
-#ifndef PT_COMBINED_TRIGGER
-#define PT_COMBINED_TRIGGER 0 // (A/B) > 0: a shading pass is due as soon as the hit and the miss queue hold a full batch TOGETHER, each at least this many
-#endif
-#ifndef PT_PUSH_SORTED
-#define PT_PUSH_SORTED 0 // quad step: 1 = the three children that are not entered go on the stack strictly by entry distance (A/B)
-#endif
 #ifndef PT_TOPUP_MIN
 #define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
                        // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
@@ -139,21 +133,13 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     const bool swap_o = in_b ? b01 : b23; // the other pair's second slot is the nearer one: push it second
     const int oa = in_b ? r0 : r2, ob = in_b ? r1 : r3;
     const bool ha = in_b ? hit[0] : hit[2], hb = in_b ? hit[1] : hit[3];
-    int x1 = swap_o ? oa : ob, x2 = swap_o ? ob : oa;
-    bool h1 = swap_o ? ha : hb, h2 = swap_o ? hb : ha;
+    const int x1 = swap_o ? oa : ob, x2 = swap_o ? ob : oa;
+    const bool h1 = swap_o ? ha : hb, h2 = swap_o ? hb : ha;
     const bool first_of_pair = in_b ? !b23 : !b01; // the nearest is the first slot of its pair
-    int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
-    bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
-#if PT_PUSH_SORTED
-    {   // all three by distance, farthest first: the partner goes where its entry distance puts it instead of always last
-        const float ko_far = in_b ? (b01 ? k0 : k1) : (b23 ? k2 : k3), ko_near = in_b ? m01 : m23; // the other pair's keys
-        const float kp = in_b ? (first_of_pair ? k3 : k2) : (first_of_pair ? k1 : k0);               // the partner's key
-        const bool p_first = kp > ko_far, p_mid = !p_first && kp > ko_near;
-        const int y1 = p_first ? x3 : x1, y2 = p_first ? x1 : (p_mid ? x3 : x2), y3 = (p_first || p_mid) ? x2 : x3;
-        const bool g1 = p_first ? h3 : h1, g2 = p_first ? h1 : (p_mid ? h3 : h2), g3 = (p_first || p_mid) ? h2 : h3;
-        x1 = y1; x2 = y2; x3 = y3; h1 = g1; h2 = g2; h3 = g3;
-    }
-#endif
+    const int x3 = in_b ? (first_of_pair ? r3 : r2) : (first_of_pair ? r1 : r0);
+    const bool h3 = in_b ? (first_of_pair ? hit[3] : hit[2]) : (first_of_pair ? hit[1] : hit[0]);
+    // (strictly by entry distance - the partner inserted where its distance puts it - costs 12 more instructions per step and saves
+    // 0.1 % of the triangle tests: C4 497 -> 515 ms, C5 3 211 -> 3 353, profiles/r04_notes.md)
     if (LDS_ENTRIES == 0x7fffffff) {
         // common instance (the caller made sure sp + 3 stays inside the LDS part): store above the top whether or not the entry is
         // pushed - the slot is free either way - and advance sp by the predicate; no branches
@@ -356,7 +342,16 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
 #endif
 enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
 // S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = chunk index (cost pre-pass: clock at the start of the pixel)
+#ifndef PT_COLOR_IN_HBM
+#define PT_COLOR_IN_HBM 0 // (A/B) 1: a slot's accumulated colour - touched once per SAMPLE, not per ray - lives in a wave-private global area, which makes
+                          // room for 128 instead of 96 slots in the wave's 10 KB of LDS
+#endif
+#define PT_COL_STRIDE 256 // slots per colour plane of that area
+#if PT_COLOR_IN_HBM
+enum { S_PIX = 0, S_RNG, S_PACK, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
+#else
 enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
+#endif
 // S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
 #define PT_FRESH 0xffffffffu // S_PIX marker: slot has no (pixel, chunk) running; S_RNG then holds the ticket it waits on, or PT_FRESH
@@ -379,7 +374,7 @@ static_assert(PT_GROUP_STACK <= 8 * PT_LDS_STACK, "a group's stack is eight colu
 static inline size_t pt_wave_state_words(int stack_entries)
 {
     int ovf = stack_entries > PT_LDS_STACK ? stack_entries - PT_LDS_STACK : 0;
-    return (size_t)(K_NFIELDS + ovf) * PT_WAVE;
+    return (size_t)(K_NFIELDS + ovf) * PT_WAVE + (PT_COLOR_IN_HBM ? 3 * PT_COL_STRIDE : 0);
 }
 
 namespace {
@@ -388,6 +383,7 @@ struct WaveCtx {
     uint32_t* lray;   // LDS
     uint32_t* lstate; // LDS
     uint8_t *rayq, *hitq, *missq;
+    uint32_t PT_AS1* colg;  // PT_COLOR_IN_HBM: colg[plane * PT_COL_STRIDE + slot]
     uint8_t* binq;          // lobe bins of the hit pass: binq[b * ns + i], b = predicted lobe (LOBE-COHERENT HIT PASSES, below)
     const uint32_t* ltab;   // LDS copy of the per-material lobe codes (PT_LOBE_TABLE words)
     uint32_t bin_head, bin_count; // ring heads / fills of the four bins, one byte each (ns <= 255)
@@ -437,10 +433,6 @@ __device__ __forceinline__ int pick_pass(const WaveCtx& w, bool starving)
     const int hits = w.hit_count + w.binned; // hits waiting for shading: not yet classified + in the lobe bins
     if (hits >= w.full_batch) return PICK_HIT;
     if (miss_ok && w.miss_count >= w.full_batch) return PICK_MISS;
-#if PT_COMBINED_TRIGGER
-    // (A/B) with topped-up passes a full batch can be made of both queues: go as soon as they hold one together
-    if (w.topup && miss_ok && hits + w.miss_count >= w.full_batch && hits >= PT_COMBINED_TRIGGER && w.miss_count >= PT_COMBINED_TRIGGER) return hits >= w.miss_count ? PICK_HIT : PICK_MISS;
-#endif
     if (w.ray_count < w.ray_low) {
         // the ray queue is about to run dry: a half-full shading pass is cheaper than idle traversal lanes (traversal is ~80 %
         // of a wave's time, shading ~12 %)
@@ -582,7 +574,11 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         if (running) {
             ps.rng = GF(S_RNG, ps_slot);
             ps.throughput = V(GFF(S_THRX, ps_slot), GFF(S_THRY, ps_slot), GFF(S_THRZ, ps_slot));
+#if PT_COLOR_IN_HBM
+            color = V(__uint_as_float(w.colg[ps_slot]), __uint_as_float(w.colg[PT_COL_STRIDE + ps_slot]), __uint_as_float(w.colg[2 * PT_COL_STRIDE + ps_slot]));
+#else
             color = V(GFF(S_COLX, ps_slot), GFF(S_COLY, ps_slot), GFF(S_COLZ, ps_slot));
+#endif
             px = (int)(pid & 0xffffu); // S_PIX holds x | y << 16
             py = (int)(pid >> 16);
             ps.depth = (int)((pack >> 16) & 63u);
@@ -645,9 +641,17 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 GF(S_QKC, ps_slot) = P.cost_out ? cost : chunk;
                 GF(S_RNG, ps_slot) = ps.rng;
                 GF(S_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
+#if PT_COLOR_IN_HBM
+                if (need_gen) { // the colour only changes when a sample ends or a work item starts
+                    w.colg[ps_slot] = __float_as_uint(color.x);
+                    w.colg[PT_COL_STRIDE + ps_slot] = __float_as_uint(color.y);
+                    w.colg[2 * PT_COL_STRIDE + ps_slot] = __float_as_uint(color.z);
+                }
+#else
                 GF(S_COLX, ps_slot) = __float_as_uint(color.x);
                 GF(S_COLY, ps_slot) = __float_as_uint(color.y);
                 GF(S_COLZ, ps_slot) = __float_as_uint(color.z);
+#endif
                 GF(S_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
                 GF(S_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
                 GF(S_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
@@ -961,13 +965,15 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     uint32_t* lray = lds0 + lds_stack * PT_WAVE;     // lray[field * ns + slot]
     uint32_t* lstate = lray + L_NFIELDS * ns;       // lstate[field * ns + slot]
     const int ovf_levels = P.stack_entries > PT_LDS_STACK ? P.stack_entries - PT_LDS_STACK : 0;
-    uint32_t PT_AS1* park = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE) + lane; // park[field * 64]
+    uint32_t PT_AS1* wave_state = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE + (PT_COLOR_IN_HBM ? 3 * PT_COL_STRIDE : 0));
+    uint32_t PT_AS1* park = wave_state + lane; // park[field * 64]
     uint32_t PT_AS1* ovf = park + K_NFIELDS * PT_WAVE;                                                                   // ovf[level * 64]
     WaveCtx w;
     w.lray = lray;
     w.lstate = lstate;
     w.ns = ns;
     w.rayq = reinterpret_cast<uint8_t*>(lstate + S_NFIELDS * ns);
+    w.colg = wave_state + (size_t)(K_NFIELDS + ovf_levels) * PT_WAVE;
     w.hitq = w.rayq + ns;
     w.missq = w.hitq + ns;
     w.binq = w.missq + ns;
