@@ -342,16 +342,7 @@ __device__ __forceinline__ void finish_chunk(const PtKernelParams& P, uint32_t c
 #endif
 enum { L_DIRX = 0, L_DIRY, L_DIRZ, L_AX, L_AY, L_AZ, L_NFIELDS };
 // S_RNG holds the ticket while the slot waits for its work item (S_PIX == PT_FRESH); S_QKC = chunk index (cost pre-pass: clock at the start of the pixel)
-#ifndef PT_COLOR_IN_HBM
-#define PT_COLOR_IN_HBM 0 // (A/B) 1: a slot's accumulated colour - touched once per SAMPLE, not per ray - lives in a wave-private global area, which makes
-                          // room for 128 instead of 96 slots in the wave's 10 KB of LDS
-#endif
-#define PT_COL_STRIDE 256 // slots per colour plane of that area
-#if PT_COLOR_IN_HBM
-enum { S_PIX = 0, S_RNG, S_PACK, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
-#else
 enum { S_PIX = 0, S_RNG, S_PACK, S_COLX, S_COLY, S_COLZ, S_THRX, S_THRY, S_THRZ, S_QKC, S_NFIELDS };
-#endif
 // S_PACK: bits 0-15 sample index within the chunk, 16-21 depth, 22-24 lobe+1, 25-31 consecutive NaN retries
 #define PT_PACK(s, depth, lobe, retries) ((uint32_t)(s) | ((uint32_t)(depth) << 16) | ((uint32_t)((lobe) + 1) << 22) | ((uint32_t)(retries) << 25))
 #define PT_FRESH 0xffffffffu // S_PIX marker: slot has no (pixel, chunk) running; S_RNG then holds the ticket it waits on, or PT_FRESH
@@ -374,7 +365,7 @@ static_assert(PT_GROUP_STACK <= 8 * PT_LDS_STACK, "a group's stack is eight colu
 static inline size_t pt_wave_state_words(int stack_entries)
 {
     int ovf = stack_entries > PT_LDS_STACK ? stack_entries - PT_LDS_STACK : 0;
-    return (size_t)(K_NFIELDS + ovf) * PT_WAVE + (PT_COLOR_IN_HBM ? 3 * PT_COL_STRIDE : 0);
+    return (size_t)(K_NFIELDS + ovf) * PT_WAVE;
 }
 
 namespace {
@@ -383,7 +374,6 @@ struct WaveCtx {
     uint32_t* lray;   // LDS
     uint32_t* lstate; // LDS
     uint8_t *rayq, *hitq, *missq;
-    uint32_t PT_AS1* colg;  // PT_COLOR_IN_HBM: colg[plane * PT_COL_STRIDE + slot]
     uint8_t* binq;          // lobe bins of the hit pass: binq[b * ns + i], b = predicted lobe (LOBE-COHERENT HIT PASSES, below)
     const uint32_t* ltab;   // LDS copy of the per-material lobe codes (PT_LOBE_TABLE words)
     uint32_t bin_head, bin_count; // ring heads / fills of the four bins, one byte each (ns <= 255)
@@ -574,11 +564,7 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
         if (running) {
             ps.rng = GF(S_RNG, ps_slot);
             ps.throughput = V(GFF(S_THRX, ps_slot), GFF(S_THRY, ps_slot), GFF(S_THRZ, ps_slot));
-#if PT_COLOR_IN_HBM
-            color = V(__uint_as_float(w.colg[ps_slot]), __uint_as_float(w.colg[PT_COL_STRIDE + ps_slot]), __uint_as_float(w.colg[2 * PT_COL_STRIDE + ps_slot]));
-#else
             color = V(GFF(S_COLX, ps_slot), GFF(S_COLY, ps_slot), GFF(S_COLZ, ps_slot));
-#endif
             px = (int)(pid & 0xffffu); // S_PIX holds x | y << 16
             py = (int)(pid >> 16);
             ps.depth = (int)((pack >> 16) & 63u);
@@ -641,17 +627,9 @@ __device__ __forceinline__ void shade_pass(const PtKernelParams& P, WaveCtx& w, 
                 GF(S_QKC, ps_slot) = P.cost_out ? cost : chunk;
                 GF(S_RNG, ps_slot) = ps.rng;
                 GF(S_PACK, ps_slot) = PT_PACK(s, ps.depth, ps.lobe, ps.retries);
-#if PT_COLOR_IN_HBM
-                if (need_gen) { // the colour only changes when a sample ends or a work item starts
-                    w.colg[ps_slot] = __float_as_uint(color.x);
-                    w.colg[PT_COL_STRIDE + ps_slot] = __float_as_uint(color.y);
-                    w.colg[2 * PT_COL_STRIDE + ps_slot] = __float_as_uint(color.z);
-                }
-#else
                 GF(S_COLX, ps_slot) = __float_as_uint(color.x);
                 GF(S_COLY, ps_slot) = __float_as_uint(color.y);
                 GF(S_COLZ, ps_slot) = __float_as_uint(color.z);
-#endif
                 GF(S_THRX, ps_slot) = __float_as_uint(ps.throughput.x);
                 GF(S_THRY, ps_slot) = __float_as_uint(ps.throughput.y);
                 GF(S_THRZ, ps_slot) = __float_as_uint(ps.throughput.z);
@@ -965,7 +943,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     uint32_t* lray = lds0 + lds_stack * PT_WAVE;     // lray[field * ns + slot]
     uint32_t* lstate = lray + L_NFIELDS * ns;       // lstate[field * ns + slot]
     const int ovf_levels = P.stack_entries > PT_LDS_STACK ? P.stack_entries - PT_LDS_STACK : 0;
-    uint32_t PT_AS1* wave_state = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE + (PT_COLOR_IN_HBM ? 3 * PT_COL_STRIDE : 0));
+    uint32_t PT_AS1* wave_state = gp(P.slot_state) + (size_t)blockIdx.x * ((size_t)(K_NFIELDS + ovf_levels) * PT_WAVE);
     uint32_t PT_AS1* park = wave_state + lane; // park[field * 64]
     uint32_t PT_AS1* ovf = park + K_NFIELDS * PT_WAVE;                                                                   // ovf[level * 64]
     WaveCtx w;
@@ -973,7 +951,6 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.lstate = lstate;
     w.ns = ns;
     w.rayq = reinterpret_cast<uint8_t*>(lstate + S_NFIELDS * ns);
-    w.colg = wave_state + (size_t)(K_NFIELDS + ovf_levels) * PT_WAVE;
     w.hitq = w.rayq + ns;
     w.missq = w.hitq + ns;
     w.binq = w.missq + ns;
