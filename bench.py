@@ -85,7 +85,7 @@ def kernel_fingerprint():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("pt_kernel.hip", "pt_device.h", "pt_types.h"):
+    for f in ("pt_kernel.hip", "pt_trace.h", "pt_device.h", "pt_types.h"):
         with open(os.path.join(ROOT, "owl-path-tracer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
