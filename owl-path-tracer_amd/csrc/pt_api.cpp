@@ -320,8 +320,6 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
     else if (k == "fallback") c->fallback = value != 0; // force the wavefront kernel's 168-VGPR fallback instance (tests)
     else if (k == "express_permille") c->express_permille = (int)(value < 0 ? -1 : (value > 500 ? 500 : value)); // -1: automatic
     else if (k == "whole") c->whole = (int)(value < 0 ? -1 : (value > 1 ? 1 : value)); // whole-pixel schedule by cost class when every pixel can have a path slot: -1 the plan decides (default), 0 never, 1 always
-    else if (k == "express_cap") c->express_cap = (int)(value < 0 ? 0 : (value > 900 ? 900 : value)); // most express waves, per mille of the resident waves (0: automatic)
-    else if (k == "express_over") c->express_over = value != 0;
     else if (k == "ns_express") c->ns_express = (int)(value < 1 ? 1 : (value > 64 ? 64 : value));
     else if (k == "groups") c->groups = (int)(value < 0 ? 0 : (value > 2 ? 2 : value)); // group walk: 0 never, 1 sparse waves (default), 2 always
     else if (k == "ploc_radius") c->ploc_radius = (int)(value < 1 ? 1 : (value > 64 ? 64 : value)); // bvh_builder 2: neighbours searched on either side
@@ -923,17 +921,17 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         const int nse = std::max(1, std::min(c->ns_express, ns));
         uint64_t want = (uint64_t)((double)c->n_pixels * permille / 1000.0);
         const int capacity = c->num_cus * bpc;
-        // at most an eighth of the ring schedule's waves, or what the bulk leaves free (option "express_cap": per mille of the resident waves)
-        const int cap_waves = c->express_cap > 0 ? (int)((long)capacity * c->express_cap / 1000) : std::max(rgrid / 8, std::min(capacity / 2, capacity - rgrid));
+        // at most an eighth of the ring schedule's waves, or what the bulk leaves free.  (Round 4 tried up to 60 % of the waves for 1-15 % of the
+        // pixels at 8-48 per wave, also with the grid oversubscribed by the express waves: world 2 351 -> 400-470 ms, world 4 269 -> 300-370,
+        // profiles/r04_notes.md 5.)
+        const int cap_waves = std::max(rgrid / 8, std::min(capacity / 2, capacity - rgrid));
         want = std::min<uint64_t>(want, (uint64_t)cap_waves * (uint64_t)nse);
         if (want > 0 && want < c->n_pixels) {
             n_express = (uint32_t)want;
             express_waves = (int)((want + (uint64_t)nse - 1) / (uint64_t)nse);
             P.ns_express = nse;
             // wave slots the bulk does not fill (a shard, a small image) hold the express waves on top of the bulk's
-            // (option "express_over": the launch has express_waves workgroups MORE than fit the chip - the express waves come first, and as
-            // they finish the hardware starts the last bulk workgroups in their place instead of leaving their wave slots empty)
-            rgrid = std::min(capacity + (c->express_over ? express_waves : 0), (int)(((long)c->n_pixels - (long)n_express + ns - 1) / ns) + express_waves);
+            rgrid = std::min(capacity, (int)(((long)c->n_pixels - (long)n_express + ns - 1) / ns) + express_waves);
             if (state_words) {
                 if ((rc = ensure(c, c->d_slots, state_words * 4 * (size_t)grid))) return rc;
                 P.slot_state = (uint32_t*)c->d_slots.p;
