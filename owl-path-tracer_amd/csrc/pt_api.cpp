@@ -737,7 +737,8 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
             ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         }
         if (ge == hipErrorInvalidConfiguration)
-            return fail(c, PT_E_LIMIT, "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
+            return fail(c, PT_E_LIMIT, use_count ? "the instrumented instance of the render kernel needs scratch in this build; such builds rendered wrong pixels and are refused (pt_kernel.hip; tests/test_abi_host.py reads hipcc's resource report)"
+                                                 : "this build of the render kernel spills registers to scratch even in its fallback instance; such builds rendered wrong pixels and are refused (pt_kernel.hip)");
         HIP_TRY(c, ge);
     }
     if (c->kernel == 2 && c->slots_per_wave == 0 && occ > 0) {
