@@ -56,17 +56,21 @@ def _cached(name, make):
         if os.path.exists(path):
             z = np.load(path, allow_pickle=False)
             return [(str(n), dict(vertices=z["v%d" % i], normals=z["n%d" % i], texcoords=z["t%d" % i], indices=z["i%d" % i])) for i, n in enumerate(z["names"])]
-    except (OSError, ValueError, KeyError):
+    except Exception:  # unreadable cache (another user's file, a stale format): generate
         pass
     ms = make()
+    tmp = "%s.%d.tmp.npz" % (path, os.getpid())  # the N ranks of one node write side by side: a name of its own each, then an atomic rename
     try:
         d = {"names": np.array([n for n, _ in ms])}
         for i, (_, m) in enumerate(ms):
             d["v%d" % i], d["n%d" % i], d["t%d" % i], d["i%d" % i] = m["vertices"], m["normals"], m["texcoords"], m["indices"]
-        np.savez(path + ".tmp.npz", **d)
-        os.replace(path + ".tmp.npz", path)
-    except OSError:
-        pass
+        np.savez(tmp, **d)
+        os.replace(tmp, path)
+    except Exception:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
     return ms
 
 

@@ -201,9 +201,8 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   chunk size - the resumability tests use it);  "census_mode", "latency": diagnostics of the instrumented build;
  *   "groups" 1 (default: a wave with few rays to trace walks them eight lanes per ray over oct nodes) | 0 (never) | 2 (always: tests),
  *   "wide_leaves" 1 (oct nodes: subtrees of <= 7 triangles are one leaf step; next pt_upload_scene), "tune6" / "tune7" (16 / 24: ray-queue
- *   level and running pixels up to which a wave counts as sparse);  "coop" / "quant": two validated experiments that are NOT in the product
- *   build (cooperative whole-line node fetch through an LDS staging area; 64-byte quad nodes with 8-bit planes) - builds made with
- *   EXTRA="-DPT_WITH_COOP=1 -DPT_WITH_QUANT=1" contain them (default on there); elsewhere setting either to 1 returns PT_E_INVALID;
+ *   level and running pixels up to which a wave counts as sparse);  "tune0" (8: a shading pass with idle lanes also takes the entries of the other
+ *   queue when that holds at least this many; > 64 = never; off by itself when an environment map is bound);
  *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" 1 | -1: lobe-coherent hit passes (a hit pass shades the hits of ONE predicted
  *   lobe at a time; -1: only when the materials can sample two or more lobes) - exists in `make lobebins` builds only (validated bit-exact, costs
  *   what it saves: profiles/r04_notes.md); the product build returns PT_E_INVALID; "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
