@@ -20,8 +20,9 @@ sys.path.insert(0, %(root)r)
 import ptamd; ptamd.load()
 from owl_path_tracer_amd.pyhost import binding as B, scene_io
 rank, world, tmp = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+dev = int(sys.argv[4]) if len(sys.argv) > 4 else rank  # (stub-collective test: every rank on device 0)
 sc = scene_io.load_scene_dir(os.path.join(%(root)r, "assets"), "cornell-box")
-ctx = B.Context(rank)
+ctx = B.Context(dev)
 ctx.upload_scene(sc["entities"], [m for _, m, _ in sc["materials"]], env=B.make_env(color=(1, 1, 1), intensity=0.0))
 idf = os.path.join(tmp, "comm_id.bin")
 if rank == 0:
@@ -53,14 +54,8 @@ def _device_count():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_library_reduce_across_processes(tmp_path, world):
-    """The root asks for the RGBA8 image, the other ranks pass no buffers at all: every rank must still enqueue the same collectives
-    (round-2 advisor finding: the RGBA8 reduce was issued only where a buffer was passed).  World 1 runs on the one-GPU boxes."""
-    if _device_count() < world:
-        pytest.skip("needs %d GPUs" % world)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT), str(r), str(world), str(tmp_path)], env=env) for r in range(world)]
+def _run_ranks(tmp_path, world, env, same_device=False):
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT), str(r), str(world), str(tmp_path)] + (["0"] if same_device else []), env=env) for r in range(world)]
     t0 = time.time()
     try:
         for p in procs:
@@ -83,3 +78,31 @@ def test_library_reduce_across_processes(tmp_path, world):
     ctx.close()
     np.testing.assert_array_equal(np.load(tmp_path / "rgb.npy").view(np.uint32), want.view(np.uint32))
     np.testing.assert_array_equal(np.load(tmp_path / "rgba8.npy"), want8)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_library_reduce_across_processes(tmp_path, world):
+    """The root asks for the RGBA8 image, the other ranks pass no buffers at all: every rank must still enqueue the same collectives
+    (round-2 advisor finding: the RGBA8 reduce was issued only where a buffer was passed).  World 1 runs on the one-GPU boxes."""
+    if _device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    _run_ranks(tmp_path, world, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_reduce_with_stub_collective(tmp_path, world):
+    """The library's N-rank plumbing with N > 1 PROCESSES on ONE GPU: every rank opens device 0 and PT_RCCL_PATH points at
+    tests/stub/fake_rccl.cpp (built here), whose ncclReduce is a blocking sum through files.  That is NOT RCCL and proves nothing
+    about RCCL - what it exercises is our side, which had never run with more than one rank (round-3 advisor finding): the unique id
+    through a file, pt_comm_init_rank per process and the pixel shard it sets, ONE reduce per frame and rank although only the root
+    passes buffers, the root's RGBA8 pack of the reduced frame, a second frame on the same communicator, teardown.  The frame on
+    rank 0 must be the single-GPU frame bit for bit (world 3 leaves ranks with different tile counts)."""
+    import shutil
+
+    gxx = shutil.which("g++")
+    if not gxx or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("g++ or the RCCL header is missing")
+    stub = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call([gxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", stub,
+                           os.path.join(ROOT, "tests", "stub", "fake_rccl.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    _run_ranks(tmp_path, world, dict(os.environ, PT_RCCL_PATH=stub), same_device=True)
