@@ -180,6 +180,11 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render path)")
+    # PT_BENCH_DEVICE (rehearsals only): every rank on ONE device - the N > 1 code path of this script on a one-GPU box, together with
+    # PT_RCCL_PATH = the stub collective of tests/stub/fake_rccl.cpp; such a line carries "rehearsal": true and is not a measurement
+    rehearsal_dev = os.environ.get("PT_BENCH_DEVICE")
+    if rehearsal_dev is not None:
+        local_rank = int(rehearsal_dev)
     torch.cuda.set_device(local_rank)
     D.init(backend="gloo")  # control plane on the CPU: no second RCCL communicator next to the library's
 
@@ -330,6 +335,8 @@ def main():
                          "vgprs": st["vgprs"], "lds_bytes": st["lds_bytes"], "grid": st["grid"], "block": st["block"]},
         }
         out["per_rank"] = per_rank
+        if rehearsal_dev is not None:
+            out["rehearsal"] = True
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_io, mats, ents, cam.as_array())
         print(json.dumps(out), flush=True)
