@@ -61,6 +61,9 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
+#ifndef PT_BOX_FMA
+#define PT_BOX_FMA 0 // (A/B) quad step: slab distances as fma(plane, 1/d, -(o/d)) - one packed fma per plane pair instead of a subtraction and a multiplication
+#endif
 #ifndef PT_TOPUP_MIN
 #define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
                        // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
@@ -90,6 +93,10 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     const f32x4 lx = ldg4(nodes4, nb), ly = ldg4(nodes4, nb + 16), lz = ldg4(nodes4, nb + 32);
     const f32x4 hx = ldg4(nodes4, nb + 48), hy = ldg4(nodes4, nb + 64), hz = ldg4(nodes4, nb + 80), cf = ldg4(nodes4, nb + 96);
     const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+#if PT_BOX_FMA
+    const float nx = -(o.x * inv.x), ny = -(o.y * inv.y), nz = -(o.z * inv.z);
+    const f32x2 nox = {nx, nx}, noy = {ny, ny}, noz = {nz, nz};
+#endif
     const f32x2 pad = {1.0000004f, 1.0000004f};
     float tn[4];
     bool hit[4];
@@ -98,9 +105,15 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
         const f32x2 lox = p ? (f32x2){lx.z, lx.w} : (f32x2){lx.x, lx.y}, loy = p ? (f32x2){ly.z, ly.w} : (f32x2){ly.x, ly.y};
         const f32x2 loz = p ? (f32x2){lz.z, lz.w} : (f32x2){lz.x, lz.y}, hix = p ? (f32x2){hx.z, hx.w} : (f32x2){hx.x, hx.y};
         const f32x2 hiy = p ? (f32x2){hy.z, hy.w} : (f32x2){hy.x, hy.y}, hiz = p ? (f32x2){hz.z, hz.w} : (f32x2){hz.x, hz.y};
+#if PT_BOX_FMA
+        const f32x2 t0x = __builtin_elementwise_fma(lox, ix, nox), t1x = __builtin_elementwise_fma(hix, ix, nox);
+        const f32x2 t0y = __builtin_elementwise_fma(loy, iy, noy), t1y = __builtin_elementwise_fma(hiy, iy, noy);
+        const f32x2 t0z = __builtin_elementwise_fma(loz, iz, noz), t1z = __builtin_elementwise_fma(hiz, iz, noz);
+#else
         const f32x2 t0x = (lox - ox) * ix, t1x = (hix - ox) * ix;
         const f32x2 t0y = (loy - oy) * iy, t1y = (hiy - oy) * iy;
         const f32x2 t0z = (loz - oz) * iz, t1z = (hiz - oz) * iz;
+#endif
         const float ta = fmax_hw(fmax_hw(fmin_hw(t0x.x, t1x.x), fmin_hw(t0y.x, t1y.x)), fmax_hw(fmin_hw(t0z.x, t1z.x), kTMin));
         const float tb = fmax_hw(fmax_hw(fmin_hw(t0x.y, t1x.y), fmin_hw(t0y.y, t1y.y)), fmax_hw(fmin_hw(t0z.y, t1z.y), kTMin));
         f32x2 tf = {fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmin_hw(fmax_hw(t0z.x, t1z.x), tbest)),
