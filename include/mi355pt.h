@@ -203,7 +203,8 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
  *   "wide_leaves" 1 (oct nodes: subtrees of <= 7 triangles are one leaf step; next pt_upload_scene), "tune6" / "tune7" (16 / 24: ray-queue
  *   level and running pixels up to which a wave counts as sparse);  "tune0" (8: a shading pass with idle lanes also takes the entries of the other
  *   queue when that holds at least this many; > 64 = never; off by itself when an environment map is bound);
- *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "lobe_bins" 1 | -1: lobe-coherent hit passes (a hit pass shades the hits of ONE predicted
+ *   "quad" 1 (default: two binary levels per 128-byte record) | 0;  "box_exact" -1 (default: slab distances by one fma per plane, the
+ *   subtracting form when the camera is more than 42 scene extents from the origin) | 0 | 1;  "lobe_bins" 1 | -1: lobe-coherent hit passes (a hit pass shades the hits of ONE predicted
  *   lobe at a time; -1: only when the materials can sample two or more lobes) - exists in `make lobebins` builds only (validated bit-exact, costs
  *   what it saves: profiles/r04_notes.md); the product build returns PT_E_INVALID; "tune4" (24: hits of one lobe that make a pass of their own);  "fallback" 1: use the wavefront kernel's 168-VGPR instance (what
  *   the library does by itself when the 128-VGPR instance of a build needs scratch). */

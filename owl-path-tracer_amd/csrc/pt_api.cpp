@@ -327,6 +327,7 @@ int pt_set_option(pt_ctx* c, const char* key, int64_t value)
         if (value && !pt_kernel_lobe_bins()) return fail(c, PT_E_INVALID, "option 'lobe_bins': this build has no lobe bins (make -C owl-path-tracer_amd/csrc lobebins)");
         c->lobe_bins = (int)(value < 0 ? -1 : (value > 1 ? 1 : value));
     } // hit passes by predicted lobe: 0 never (default), 1 whenever possible, -1 when the scene has two or more lobes
+    else if (k == "box_exact") c->box_exact = (int)(value < 0 ? -1 : (value > 0 ? 1 : 0)); // slab test form: -1 automatic (fma unless the camera is far outside the scene), 0 fma, 1 subtracting
     else if (k == "quad") c->quad = value != 0; // wavefront kernel: quad nodes (two binary levels per fetch), next pt_render
     else if (k == "node_pairs") c->node_pairs = value != 0;
     else if (k == "leaf_align") c->leaf_align = (int)(value < 1 ? 1 : (value > 8 ? 8 : value));
@@ -881,6 +882,13 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     }
 
     std::memcpy(P.cam, cam, sizeof(float) * 12);
+    {   // the fma form of the slab test (pt_kernel.hip, node4_step) displaces a plane by |o| 2^-24; the boxes are padded by 1e-5 x the scene
+        // extent (bvh.pad): exact form when the camera is so far from the origin that this would eat a quarter of the padding
+        const float reach = c->bvh.pad * 4194304.0f; // pad x 2^22 = 42 scene extents
+        float far_o = 0.0f;
+        for (int a = 0; a < 3; ++a) far_o = std::max(far_o, std::fabs(cam->origin[a]));
+        P.box_exact = (c->box_exact > 0 || (c->box_exact < 0 && !(far_o <= reach))) ? 1 : 0;
+    }
     P.pixel_ids = (const uint32_t*)c->d_pixels.p;
     P.n_pixels = c->n_pixels;
     P.rng_state = (uint32_t*)c->d_rng.p;

@@ -63,7 +63,7 @@ struct pt_ctx {
     bool queue_valid = false;
 
     // options
-    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, express_permille = -1, ns_express = 8, whole = -1, lobe_bins = 0;
+    int spp_per_launch = 0, count = 0, blocks_per_cu = 0, leaf_size = 4, max_bvh_depth = 48, kernel = 2, slots_per_wave = 0, chunk_spp = 64, chunk_tail_min = -1, schedule = 1, prepass_spp = 0, census_mode = 0, sticky_pct = -1, latency = 0, cost_radius = 2, timeline = 0, node_pairs = 0, leaf_align = 1, bvh_builder = 3, quad = 1, groups = 1, wide_leaves = 1, fallback = 0, ploc_radius = 16, express_permille = -1, ns_express = 8, whole = -1, lobe_bins = 0, box_exact = -1;
     int tune[8] = {};
 
     void* comm = nullptr;   // ncclComm_t once pt_comm_init_rank / pt_group_create attached one (pt_comm.cpp)

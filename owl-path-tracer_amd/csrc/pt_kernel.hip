@@ -61,9 +61,6 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
-#ifndef PT_BOX_FMA
-#define PT_BOX_FMA 0 // (A/B) quad step: slab distances as fma(plane, 1/d, -(o/d)) - one packed fma per plane pair instead of a subtraction and a multiplication
-#endif
 #ifndef PT_TOPUP_MIN
 #define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
                        // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
@@ -86,17 +83,21 @@ namespace {
 // pay - whole-line cooperative fetches through an LDS staging area, 64-byte records with 8-bit planes - live in variants/.)
 template <int STRIDE, int LDS_ENTRIES, bool CENSUS = false>
 __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, uint32_t* stack, uint32_t PT_AS1* ovf, v3 o, v3 inv, float tbest, int& cur, int& sp,
-                                           uint32_t* n_nohit = nullptr, uint32_t* n_beyond = nullptr)
+                                           const bool exact, uint32_t* n_nohit = nullptr, uint32_t* n_beyond = nullptr)
 {
     bool crossed = false; // CENSUS: the ray crosses some slot's box when the bound of the best hit is ignored
     const size_t nb = (size_t)(uint32_t)cur * sizeof(PtNode4);
     const f32x4 lx = ldg4(nodes4, nb), ly = ldg4(nodes4, nb + 16), lz = ldg4(nodes4, nb + 32);
     const f32x4 hx = ldg4(nodes4, nb + 48), hy = ldg4(nodes4, nb + 64), hz = ldg4(nodes4, nb + 80), cf = ldg4(nodes4, nb + 96);
+    // Slab distances (round 4): fma(plane, 1/d, -(o/d)) - one packed fma per pair of planes instead of a subtraction and a multiplication
+    // (24 of the step's ~150 VALU operations; C4 492 -> 484-486 ms, C3 149 -> 146).  Against (plane - o) * (1/d) the distance is off by
+    // |o/d| 2^-24, i.e. the plane seems displaced by |o| 2^-24 in space: rays start on surfaces or at the camera, the boxes are padded by
+    // 1e-5 x the scene extent, and the host switches to the subtracting form (`exact`) for a camera farther than 40 extents from the
+    // origin (pt_api.cpp) - the test stays conservative with respect to every hit the triangle test can report, and the triangle test
+    // decides the image.  inf - inf (a direction component of exactly 0) gives NaN, which min / max ignore: that axis then never culls.
     const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-#if PT_BOX_FMA
     const float nx = -(o.x * inv.x), ny = -(o.y * inv.y), nz = -(o.z * inv.z);
     const f32x2 nox = {nx, nx}, noy = {ny, ny}, noz = {nz, nz};
-#endif
     const f32x2 pad = {1.0000004f, 1.0000004f};
     float tn[4];
     bool hit[4];
@@ -105,15 +106,16 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
         const f32x2 lox = p ? (f32x2){lx.z, lx.w} : (f32x2){lx.x, lx.y}, loy = p ? (f32x2){ly.z, ly.w} : (f32x2){ly.x, ly.y};
         const f32x2 loz = p ? (f32x2){lz.z, lz.w} : (f32x2){lz.x, lz.y}, hix = p ? (f32x2){hx.z, hx.w} : (f32x2){hx.x, hx.y};
         const f32x2 hiy = p ? (f32x2){hy.z, hy.w} : (f32x2){hy.x, hy.y}, hiz = p ? (f32x2){hz.z, hz.w} : (f32x2){hz.x, hz.y};
-#if PT_BOX_FMA
-        const f32x2 t0x = __builtin_elementwise_fma(lox, ix, nox), t1x = __builtin_elementwise_fma(hix, ix, nox);
-        const f32x2 t0y = __builtin_elementwise_fma(loy, iy, noy), t1y = __builtin_elementwise_fma(hiy, iy, noy);
-        const f32x2 t0z = __builtin_elementwise_fma(loz, iz, noz), t1z = __builtin_elementwise_fma(hiz, iz, noz);
-#else
-        const f32x2 t0x = (lox - ox) * ix, t1x = (hix - ox) * ix;
-        const f32x2 t0y = (loy - oy) * iy, t1y = (hiy - oy) * iy;
-        const f32x2 t0z = (loz - oz) * iz, t1z = (hiz - oz) * iz;
-#endif
+        f32x2 t0x, t1x, t0y, t1y, t0z, t1z;
+        if (exact) { // wave-uniform
+            t0x = (lox - ox) * ix; t1x = (hix - ox) * ix;
+            t0y = (loy - oy) * iy; t1y = (hiy - oy) * iy;
+            t0z = (loz - oz) * iz; t1z = (hiz - oz) * iz;
+        } else {
+            t0x = __builtin_elementwise_fma(lox, ix, nox); t1x = __builtin_elementwise_fma(hix, ix, nox);
+            t0y = __builtin_elementwise_fma(loy, iy, noy); t1y = __builtin_elementwise_fma(hiy, iy, noy);
+            t0z = __builtin_elementwise_fma(loz, iz, noz); t1z = __builtin_elementwise_fma(hiz, iz, noz);
+        }
         const float ta = fmax_hw(fmax_hw(fmin_hw(t0x.x, t1x.x), fmin_hw(t0y.x, t1y.x)), fmax_hw(fmin_hw(t0z.x, t1z.x), kTMin));
         const float tb = fmax_hw(fmax_hw(fmin_hw(t0x.y, t1x.y), fmin_hw(t0y.y, t1y.y)), fmax_hw(fmin_hw(t0z.y, t1z.y), kTMin));
         f32x2 tf = {fmin_hw(fmin_hw(fmax_hw(t0x.x, t1x.x), fmax_hw(t0y.x, t1y.x)), fmin_hw(fmax_hw(t0z.x, t1z.x), tbest)),
@@ -848,7 +850,7 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
             float tn = 0.0f;
             const int ref = __float_as_int(c1.z);
             bool hit = false;
-            if (is_node) hit = box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
+            if (is_node) hit = P.box_exact ? box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn) : box_test_fma(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
             // entry distance with the child index in its low bits: unique within the group, ordered like the distance (tn >= kTMin > 0)
             const uint32_t key = hit ? ((__float_as_uint(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
             uint32_t kmin = umin_(key, dpp_xor1(key));
@@ -974,6 +976,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.binned = 0;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtNode4* __restrict__ nodes4 = P.nodes4;
+    const bool box_exact = P.box_exact != 0; // node4_step: the subtracting slab form (camera far outside the scene)
     const PtTri* __restrict__ tris = P.tris;
 
 #define LF(f, s) lray[(f) * ns + (s)]
@@ -1191,7 +1194,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                             if (rep >= n_reps) break;
                             if (cur >= 0) {
                                 if (COUNT) cn.nodes += nodes4 ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
-                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, COUNT>(nodes4, stack, ovf, o, inv, h.t, cur, sp, &cn.cull_nohit, &cn.cull_beyond);
+                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, COUNT>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact, &cn.cull_nohit, &cn.cull_beyond);
                                 else if (COUNT) node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth); // the one-level walk exists in the instrumented instance only
                                 PT_STASH_LEAF(0x7fffffff);
                             }
@@ -1201,7 +1204,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
 #endif
                     } else if (cur >= 0) { // some stack of the wave is about to leave LDS (rare): per-lane fetch, overflow-aware pushes
                         if (COUNT) cn.nodes += nodes4 ? 2 : 1;
-                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp);
+                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact);
                         else if (COUNT) node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth);
                         if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;

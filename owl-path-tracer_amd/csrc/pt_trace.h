@@ -59,6 +59,20 @@ __device__ __forceinline__ bool box_test(float bminx, float bminy, float bminz, 
     return tn <= tf * 1.0000004f;
 }
 
+// The same test with the slab distances as fma(bound, inv, -(o * inv)): see node4_step (pt_kernel.hip) for the error bound and when the
+// host asks for the subtracting form instead.
+__device__ __forceinline__ bool box_test_fma(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, v3 o, v3 inv, float tbest, float& tnear)
+{
+    const float nx = -(o.x * inv.x), ny = -(o.y * inv.y), nz = -(o.z * inv.z);
+    float t0x = fma_(bminx, inv.x, nx), t1x = fma_(bmaxx, inv.x, nx);
+    float t0y = fma_(bminy, inv.y, ny), t1y = fma_(bmaxy, inv.y, ny);
+    float t0z = fma_(bminz, inv.z, nz), t1z = fma_(bmaxz, inv.z, nz);
+    float tn = fmax_hw(fmax_hw(fmin_hw(t0x, t1x), fmin_hw(t0y, t1y)), fmax_hw(fmin_hw(t0z, t1z), kTMin));
+    float tf = fmin_hw(fmin_hw(fmax_hw(t0x, t1x), fmax_hw(t0y, t1y)), fmin_hw(fmax_hw(t0z, t1z), tbest));
+    tnear = tn;
+    return tn <= tf * 1.0000004f;
+}
+
 // Reciprocal direction of a ray FOR THE SLAB TESTS of the wavefront kernel: v_rcp_f32 (1 ulp) instead of the correctly rounded division
 // (ten instructions each, three per ray, in the refill step every lane runs through).  A slab distance is then off by a relative
 // 2^-23 at most, i.e. a plane seems displaced by < 1.2e-7 x its distance from the ray origin - every box is padded by 1e-5 x the scene

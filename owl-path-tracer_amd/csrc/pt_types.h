@@ -158,6 +158,7 @@ struct PtKernelParams {
     int32_t root8;             // root reference into nodes8 (leaf code if the scene is tiny)
     int32_t groups;            // group walk: 0 = never, 1 = when a wave has few rays to trace (sparse wave), 2 = always (tests)
     int32_t tune[8];           // scheduler knobs (pt_set_option "tune0".."tune7"; 0 = built-in default), see pt_kernel.hip
+    int32_t box_exact;         // wavefront kernel: 1 = slab distances as (plane - o) * (1 / d) instead of the fma form (camera farther than 40 scene extents from the origin)
     const uint32_t* lobe_codes; // PT_LOBE_TABLE words: lobe thresholds per material (pt_lobe_code), index = material + 1
     int32_t lobe_bins;         // wavefront kernel: 1 = hit passes shade one predicted lobe at a time (pt_kernel.hip, LOBE-COHERENT HIT PASSES)
     uint32_t hit_slot_mask;    // 0x00ffffff when PtTri::id is packed as id << 8 | (material + 1) (then a hit's material rides in the top byte of its

@@ -516,6 +516,35 @@ def test_empty_rank_and_world8_sum(gpu, cornell):
     np.testing.assert_array_equal(acc8, full8)
 
 
+def test_slab_test_forms_and_far_camera(gpu, orc, cornell):
+    """The quad step computes slab distances as fma(plane, 1/d, -(o/d)) (round 4) and the host switches to (plane - o) * (1/d) for a camera
+    far outside the scene (pt_api.cpp, box_exact): both forms must give the oracle's image - boxes are conservative either way - and so
+    must a camera 3 000 units away (300 scene extents), where the fma form's error would exceed the boxes' padding."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    S = orc.Scene(cornell["flat"])
+    oenv = orc.make_env(color=(1, 1, 1), intensity=0.0)
+    W, H = 96, 72
+    cam = _cam(cornell, W, H)
+    want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, 40, 16)
+    try:
+        for form in (0, 1, -1):
+            gpu.set_option("box_exact", form)
+            got, _ = gpu.render(cam, W, H, 40, 16)
+            assert_bitwise(got, want, "slab form %d" % form)
+            gpu.set_option("groups", 2)  # the group walk has both forms too
+            got, _ = gpu.render(cam, W, H, 40, 16)
+            gpu.set_option("groups", 1)
+            assert_bitwise(got, want, "slab form %d, group walk" % form)
+    finally:
+        gpu.set_option("box_exact", -1)
+        gpu.set_option("groups", 1)
+    far = mkcam([3000.0, 1.0, 0.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0], 0.05, W, H)
+    got, _ = gpu.render(far, W, H, 40, 16)
+    want, _, _ = S.render(_ocam(orc, far), oenv, W, H, 40, 16)
+    assert got.max() > 0.0
+    assert_bitwise(got, want, "camera 3000 units away (automatic: subtracting form)")
+
+
 def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
     """option kernel=1 (persistent lane-per-pixel scheduler) must produce the same bits as the default wavefront scheduler."""
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
