@@ -61,6 +61,9 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
+#ifndef PT_BOX_FORM
+#define PT_BOX_FORM 0 // slab test of the quad step: 0 = fma form with the subtracting form for far cameras behind a run-time switch, 1 = fma only, 2 = subtracting only (A/B)
+#endif
 #ifndef PT_TOPUP_MIN
 #define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
                        // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
@@ -107,7 +110,7 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
         const f32x2 loz = p ? (f32x2){lz.z, lz.w} : (f32x2){lz.x, lz.y}, hix = p ? (f32x2){hx.z, hx.w} : (f32x2){hx.x, hx.y};
         const f32x2 hiy = p ? (f32x2){hy.z, hy.w} : (f32x2){hy.x, hy.y}, hiz = p ? (f32x2){hz.z, hz.w} : (f32x2){hz.x, hz.y};
         f32x2 t0x, t1x, t0y, t1y, t0z, t1z;
-        if (exact) { // wave-uniform
+        if (PT_BOX_FORM == 2 || (PT_BOX_FORM == 0 && exact)) { // wave-uniform
             t0x = (lox - ox) * ix; t1x = (hix - ox) * ix;
             t0y = (loy - oy) * iy; t1y = (hiy - oy) * iy;
             t0z = (loz - oz) * iz; t1z = (hiz - oz) * iz;
