@@ -707,6 +707,13 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     // walks (pixel, chunk) tickets; spp_per_launch, if set, becomes its chunk size so that the resumability tests cover it.
     PtKernelParams P;
     fill_params(c, P);
+    {   // the fma form of the slab test (pt_kernel.hip, node4_step) displaces a plane by |o| 2^-24; the boxes are padded by 1e-5 x the scene
+        // extent (bvh.pad): exact form when the camera is so far from the origin that this would eat a quarter of the padding
+        const float reach = c->bvh.pad * 4194304.0f; // pad x 2^22 = 42 scene extents
+        float far_o = 0.0f;
+        for (int a = 0; a < 3; ++a) far_o = std::max(far_o, std::fabs(cam->origin[a]));
+        P.box_exact = (c->box_exact > 0 || (c->box_exact < 0 && !(far_o <= reach))) ? 1 : 0;
+    }
     if (c->kernel == 2 && c->quad && !c->nodes4.empty()) { // the wavefront kernel walks the quad nodes: own root and stack bound
         P.nodes4 = (const PtNode4*)c->d_nodes4.p;
         P.root = c->root4;
@@ -732,10 +739,10 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     const int use_count = (c->count || (c->kernel == 2 && !P.nodes4)) ? 1 : 0;
     int variant = c->kernel == 2 && c->fallback && !use_count ? 3 : c->kernel;
     {
-        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+        hipError_t ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, P.box_exact, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         if (ge == hipErrorInvalidConfiguration && variant == 2 && !use_count) {
             variant = 3;
-            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
+            ge = pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, P.box_exact, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels);
         }
         if (ge == hipErrorInvalidConfiguration)
             return fail(c, PT_E_LIMIT, use_count ? "the instrumented instance of the render kernel needs scratch in this build; such builds rendered wrong pixels and are refused (pt_kernel.hip; tests/test_abi_host.py reads hipcc's resource report)"
@@ -747,7 +754,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         long fit = (long)c->n_pixels / ((long)c->num_cus * 8);
         if (fit < want_ns) {
             want_ns = (int)std::max(64L, fit);
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, P.box_exact, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     if (occ < 1) return fail(c, PT_E_LIMIT, "render kernel does not fit a CU (LDS %zu bytes, BVH depth %d)", lds, c->bvh.depth);
@@ -767,7 +774,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         for (int nsd = 96; nsd <= 104 && !tiers; nsd += 8) { // 16 waves per CU up to 104 slots
             if (c->whole < 1 && (long)c->n_pixels + (long)PT_MAX_TIERS * nsd > capacity * nsd) continue; // (one partly filled wave per class)
             want_ns = nsd;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, P.box_exact, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
             if (occ >= bpc && ns == nsd) {
                 tiers = true;
                 ring_grid = (int)std::max(1L, std::min(((long)c->n_pixels + ns - 1) / ns, capacity)); // what the ring schedule would launch
@@ -776,7 +783,7 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
         }
         if (!tiers) {
             want_ns = default_ns;
-            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
+            HIP_TRY(c, pt_kernel_geometry(variant, use_count, P.stack_entries, group_entries, want_ns, P.lobe_bins, P.box_exact, &block, &lds, &ns, &state_words, &vg, &occ, &P.lds_levels));
         }
     }
     // the tier plan lives on the cost estimate: twice the samples (1/8 shard of C4 218 -> 201 ms; a throughput-bound frame gains nothing)
@@ -882,13 +889,6 @@ int pt_render_device(pt_ctx* c, const pt_camera* cam, int32_t W, int32_t H, int3
     }
 
     std::memcpy(P.cam, cam, sizeof(float) * 12);
-    {   // the fma form of the slab test (pt_kernel.hip, node4_step) displaces a plane by |o| 2^-24; the boxes are padded by 1e-5 x the scene
-        // extent (bvh.pad): exact form when the camera is so far from the origin that this would eat a quarter of the padding
-        const float reach = c->bvh.pad * 4194304.0f; // pad x 2^22 = 42 scene extents
-        float far_o = 0.0f;
-        for (int a = 0; a < 3; ++a) far_o = std::max(far_o, std::fabs(cam->origin[a]));
-        P.box_exact = (c->box_exact > 0 || (c->box_exact < 0 && !(far_o <= reach))) ? 1 : 0;
-    }
     P.pixel_ids = (const uint32_t*)c->d_pixels.p;
     P.n_pixels = c->n_pixels;
     P.rng_state = (uint32_t*)c->d_rng.p;

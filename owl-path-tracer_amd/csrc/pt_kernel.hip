@@ -61,9 +61,6 @@
 #define PT_WITH_LOBE_BINS 0 // lobe-coherent hit passes (option "lobe_bins"): validated bit-exact, but they cost what they save, and their 2 KB of code cost
                             // the product instance 1 % even when switched off (profiles/r04_notes.md) - `make lobebins` builds the library with them
 #endif
-#ifndef PT_BOX_FORM
-#define PT_BOX_FORM 0 // slab test of the quad step: 0 = fma form with the subtracting form for far cameras behind a run-time switch, 1 = fma only, 2 = subtracting only (A/B)
-#endif
 #ifndef PT_TOPUP_MIN
 #define PT_TOPUP_MIN 8 // a shading pass with idle lanes also takes entries of the other queue when that holds at least this many (option "tune0"; > 64 = never):
                        // fewer, fuller passes - C4 497-500 -> 491-492 ms, C2 72.6-73.2 -> 70.8 (profiles/r04_notes.md); not with an environment map, whose
@@ -95,9 +92,10 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     // Slab distances (round 4): fma(plane, 1/d, -(o/d)) - one packed fma per pair of planes instead of a subtraction and a multiplication
     // (24 of the step's ~150 VALU operations; C4 492 -> 484-486 ms, C3 149 -> 146).  Against (plane - o) * (1/d) the distance is off by
     // |o/d| 2^-24, i.e. the plane seems displaced by |o| 2^-24 in space: rays start on surfaces or at the camera, the boxes are padded by
-    // 1e-5 x the scene extent, and the host switches to the subtracting form (`exact`) for a camera farther than 40 extents from the
-    // origin (pt_api.cpp) - the test stays conservative with respect to every hit the triangle test can report, and the triangle test
-    // decides the image.  inf - inf (a direction component of exactly 0) gives NaN, which min / max ignore: that axis then never culls.
+    // 1e-5 x the scene extent, and the host launches the instances with the subtracting form (`exact`) for a camera farther than 42
+    // extents from the origin (pt_api.cpp) - the test stays conservative with respect to every hit the triangle test can report, and
+    // the triangle test decides the image.  inf - inf (a direction component of exactly 0) gives NaN, which min / max ignore: that axis
+    // then never culls.  (Both forms behind a run-time switch in ONE instance cost 4 %: C4 486 -> 508 ms, profiles/r04_notes.md.)
     const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const float nx = -(o.x * inv.x), ny = -(o.y * inv.y), nz = -(o.z * inv.z);
     const f32x2 nox = {nx, nx}, noy = {ny, ny}, noz = {nz, nz};
@@ -110,7 +108,7 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
         const f32x2 loz = p ? (f32x2){lz.z, lz.w} : (f32x2){lz.x, lz.y}, hix = p ? (f32x2){hx.z, hx.w} : (f32x2){hx.x, hx.y};
         const f32x2 hiy = p ? (f32x2){hy.z, hy.w} : (f32x2){hy.x, hy.y}, hiz = p ? (f32x2){hz.z, hz.w} : (f32x2){hz.x, hz.y};
         f32x2 t0x, t1x, t0y, t1y, t0z, t1z;
-        if (PT_BOX_FORM == 2 || (PT_BOX_FORM == 0 && exact)) { // wave-uniform
+        if (exact) { // a compile-time constant in the product instances (see pt_render_wave_kernel: EXACT)
             t0x = (lox - ox) * ix; t1x = (hix - ox) * ix;
             t0y = (loy - oy) * iy; t1y = (hiy - oy) * iy;
             t0z = (loz - oz) * iz; t1z = (hiz - oz) * iz;
@@ -748,7 +746,7 @@ __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b
 // groups keep their registers there and their stacks in LDS, and the next traversal phase of the wave is a group phase again
 // (n_parked > 0 on entry: resume).  Returns the number of parked lanes.
 template <bool COUNT>
-__device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx& w, int lane, uint32_t* stack0, uint32_t PT_AS1* park, int n_parked, Counters& cn)
+__device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx& w, int lane, uint32_t* stack0, uint32_t PT_AS1* park, int n_parked, Counters& cn, const bool box_exact)
 {
     const int ns = w.ns;
     uint32_t* lray = w.lray;
@@ -853,7 +851,7 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
             float tn = 0.0f;
             const int ref = __float_as_int(c1.z);
             bool hit = false;
-            if (is_node) hit = P.box_exact ? box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn) : box_test_fma(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
+            if (is_node) hit = box_exact ? box_test(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn) : box_test_fma(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, o, inv, h.t, tn);
             // entry distance with the child index in its low bits: unique within the group, ordered like the distance (tn >= kTMin > 0)
             const uint32_t key = hit ? ((__float_as_uint(tn) & ~7u) | (uint32_t)sub) : 0xffffffffu;
             uint32_t kmin = umin_(key, dpp_xor1(key));
@@ -945,7 +943,9 @@ __device__ __forceinline__ int traverse_groups(const PtKernelParams& P, WaveCtx&
 #ifndef PT_FALLBACK_WAVES
 #define PT_FALLBACK_WAVES 3
 #endif
-template <bool COUNT, int WAVES>
+//   EXACT: the slab tests use the subtracting form (camera far outside the scene: node4_step) - instances of their own, so that the product
+//   instances carry one form only; the instrumented instance switches at run time (P.box_exact).
+template <bool COUNT, int WAVES, bool EXACT>
 __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const PtKernelParams* __restrict__ Pp)
 {
     // The parameter block lives in HBM and is read with scalar loads where it is used.  Passed by value it arrives as
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.binned = 0;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtNode4* __restrict__ nodes4 = P.nodes4;
-    const bool box_exact = P.box_exact != 0; // node4_step: the subtracting slab form (camera far outside the scene)
+    const bool box_exact = EXACT || (COUNT && P.box_exact != 0); // node4_step / group walk: the subtracting slab form (camera far outside the scene)
     const PtTri* __restrict__ tris = P.tris;
 
 #define LF(f, s) lray[(f) * ns + (s)]
@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
             if (COUNT) { cn.sched[18] += 1; cn.cyc[6] += __builtin_amdgcn_s_memtime() - t0; }
         } else if (P.nodes8 != nullptr && (n_parked == 0 ? (P.groups == 2 || (w.ray_count <= grp_max_rays && w.n_run <= grp_max_run)) : parked_groups)) {
             // sparse wave: eight lanes per ray; unfinished groups stay parked for the wave's next traversal phase, which is then a group phase too
-            n_parked = traverse_groups<COUNT>(P, w, lane, lds0, park, n_parked, cn);
+            n_parked = traverse_groups<COUNT>(P, w, lane, lds0, park, n_parked, cn, box_exact);
             parked_groups = true;
             if (COUNT) { cn.grp[0] += 1; cn.grp_cyc += __builtin_amdgcn_s_memtime() - t0; }
         } else {
@@ -1279,16 +1279,19 @@ extern "C" hipError_t pt_launch_render(const PtKernelParams* p, const PtKernelPa
                                        hipStream_t stream, int count)
 {
     if (variant == 1) return pt_launch_render_lane(p, grid, lds_bytes, stream, count); // pt_kernel_aux.hip
-    if (count) hipLaunchKernelGGL((pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
-    else if (variant == 3) hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_FALLBACK_WAVES>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
-    else hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_WAVES_PER_EU>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+    const bool exact = p->box_exact != 0;
+    if (count) hipLaunchKernelGGL((pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU, false>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+    else if (variant == 3 && exact) hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_FALLBACK_WAVES, true>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+    else if (variant == 3) hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_FALLBACK_WAVES, false>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+    else if (exact) hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_WAVES_PER_EU, true>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
+    else hipLaunchKernelGGL((pt_render_wave_kernel<false, PT_WAVES_PER_EU, false>), dim3(grid), dim3(PT_WAVE), lds_bytes, stream, d_params);
     return hipGetLastError();
 }
 
 // Launch geometry of a render variant (1: lane per pixel, 2: wavefront kernel, 3: the wavefront kernel's 168-VGPR fallback
 // instance): block size, dynamic LDS bytes, pixels a block keeps in flight (ns is chosen here for the wavefront kernel), per-block
 // global state words, registers, occupancy.  hipErrorInvalidConfiguration: the instance needs scratch (see below).
-extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int* block, size_t* lds_bytes, int* ns,
+extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int exact, int* block, size_t* lds_bytes, int* ns,
                                          size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels)
 {
     if (variant == 1) { // pt_kernel_aux.hip
@@ -1296,8 +1299,9 @@ extern "C" hipError_t pt_kernel_geometry(int variant, int count, int stack_entri
         *state_words_per_block = 0;
         return pt_lane_kernel_geometry(count, stack_entries, block, lds_bytes, ns, vgprs, max_blocks_per_cu);
     }
-    const void* fn = count ? (const void*)pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU>
-                           : (variant == 3 ? (const void*)pt_render_wave_kernel<false, PT_FALLBACK_WAVES> : (const void*)pt_render_wave_kernel<false, PT_WAVES_PER_EU>);
+    const void* fn = count ? (const void*)pt_render_wave_kernel<true, PT_COUNT_WAVES_PER_EU, false>
+                     : variant == 3 ? (exact ? (const void*)pt_render_wave_kernel<false, PT_FALLBACK_WAVES, true> : (const void*)pt_render_wave_kernel<false, PT_FALLBACK_WAVES, false>)
+                                    : (exact ? (const void*)pt_render_wave_kernel<false, PT_WAVES_PER_EU, true> : (const void*)pt_render_wave_kernel<false, PT_WAVES_PER_EU, false>);
     int n = want_ns < 16 ? 16 : (want_ns > 255 ? 255 : want_ns);
     if (bins) n = (n + 3) & ~3; // the lobe-code table follows the byte queues: keep it word aligned
     if (n > 252) n = 252;

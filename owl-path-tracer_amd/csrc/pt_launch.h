@@ -16,7 +16,7 @@ size_t pt_sort_scratch_bytes(uint32_t n);
 hipError_t pt_launch_plan_tiers(const uint32_t* scratch, uint32_t n, int capacity, int ns, int force, uint32_t* tiers, hipStream_t stream);
 hipError_t pt_launch_sort_pixels(const uint8_t* cost_img, int W, int H, int radius, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t c0, uint32_t* scratch,
                                  uint8_t* bucket, hipStream_t stream);
-hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int* block, size_t* lds_bytes, int* ns,
+hipError_t pt_kernel_geometry(int variant, int count, int stack_entries, int group_entries, int want_ns, int bins, int exact, int* block, size_t* lds_bytes, int* ns,
                               size_t* state_words_per_block, int* vgprs, int* max_blocks_per_cu, int* lds_levels);
 int pt_debug_block(void);
 int pt_kernel_lobe_bins(void);

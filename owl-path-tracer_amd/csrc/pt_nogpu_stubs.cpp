@@ -13,7 +13,7 @@ hipError_t pt_launch_debug(const PtKernelParams*, int, const float*, int, float*
 size_t pt_sort_scratch_bytes(uint32_t) { return 16; }
 hipError_t pt_launch_plan_tiers(const uint32_t*, uint32_t, int, int, int, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t pt_launch_sort_pixels(const uint8_t*, int, int, int, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t pt_kernel_geometry(int, int, int, int, int, int, int*, size_t*, int*, size_t*, int*, int*, int*) { return hipErrorNotSupported; }
+hipError_t pt_kernel_geometry(int, int, int, int, int, int, int, int*, size_t*, int*, size_t*, int*, int*, int*) { return hipErrorNotSupported; }
 int pt_debug_block(void) { return 256; }
 int pt_kernel_lobe_bins(void) { return 0; }
 size_t pt_lbvh_workspace_bytes(int) { return 16; }
