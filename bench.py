@@ -85,11 +85,12 @@ GOLDEN_CRC = os.path.join(ROOT, "tests", "golden", "c4_frame_crc.json")
 
 
 def kernel_fingerprint():
-    """sha256 of the render kernel's sources: PMC numbers are only quoted for the build they were measured on."""
+    """sha256 of the render kernel's sources and of the Makefile (its code-generation flags): PMC numbers are only quoted for the
+    build they were measured on."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("pt_kernel.hip", "pt_trace.h", "pt_device.h", "pt_types.h"):
+    for f in ("pt_kernel.hip", "pt_trace.h", "pt_device.h", "pt_types.h", "Makefile"):
         with open(os.path.join(ROOT, "owl-path-tracer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -979,6 +979,7 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
     w.binned = 0;
     const PtNode* __restrict__ nodes = P.nodes;
     const PtNode4* __restrict__ nodes4 = P.nodes4;
+    const bool quad = !COUNT || nodes4 != nullptr; // the product instances walk quad nodes only (pt_api.cpp launches the instrumented one otherwise): a compile-time fact there
     const bool box_exact = EXACT || (COUNT && P.box_exact != 0); // node4_step / group walk: the subtracting slab form (camera far outside the scene)
     const PtTri* __restrict__ tris = P.tris;
 
@@ -1181,14 +1182,14 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                     // (1 x 1 -> 2 x up to 3: C4 626 -> 599 ms, its 1/8 shard 480 -> 435 ms, C2 98 -> 91 ms).
                     // every push of a burst must stay inside the LDS part of the stack for the common instance: one push per step when
                     // walking PtNode[], up to three per quad-node step
-                    const int n_reps = nodes4 ? PT_QUAD_REPS : PT_NODE_REPS;
-                    const int sp_lim = nodes4 ? PT_LDS_STACK - 3 * PT_QUAD_REPS : PT_LDS_STACK - PT_NODE_REPS;
+                    const int n_reps = quad ? PT_QUAD_REPS : PT_NODE_REPS;
+                    const int sp_lim = quad ? PT_LDS_STACK - 3 * PT_QUAD_REPS : PT_LDS_STACK - PT_NODE_REPS;
                     if (__ballot(sp > sp_lim) == 0ull) {
 #if PT_NODE_KEEP > 0
                       // a sparse wave (adapt): the bursts go on while at least half of the lanes that started them want another step, up to twice as many
                       const int n_node0 = popc64(m_node);
                       const int keep = w.adapt && n_node0 < 2 * PT_NODE_KEEP ? (n_node0 + 1) / 2 : PT_NODE_KEEP;
-                      const int max_bursts = (w.adapt && n_node0 < PT_NODE_KEEP ? 2 * PT_NODE_BURSTS : PT_NODE_BURSTS) * (PT_NODE_REPS / (nodes4 ? PT_QUAD_REPS : PT_NODE_REPS));
+                      const int max_bursts = (w.adapt && n_node0 < PT_NODE_KEEP ? 2 * PT_NODE_BURSTS : PT_NODE_BURSTS) * (PT_NODE_REPS / (quad ? PT_QUAD_REPS : PT_NODE_REPS));
                       for (int burst = 0; burst < max_bursts; ++burst) {
                         if (burst > 0 && (popc64(__ballot(cur >= 0)) < keep || __ballot(sp > sp_lim) != 0ull)) break;
 #endif
@@ -1196,8 +1197,8 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                         for (int rep = 0; rep < PT_NODE_REPS; ++rep) {
                             if (rep >= n_reps) break;
                             if (cur >= 0) {
-                                if (COUNT) cn.nodes += nodes4 ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
-                                if (nodes4) node4_step<PT_WAVE, 0x7fffffff, COUNT>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact, &cn.cull_nohit, &cn.cull_beyond);
+                                if (COUNT) cn.nodes += quad ? 2 : 1; // a quad node is two binary nodes' worth of boxes (128 B)
+                                if (quad) node4_step<PT_WAVE, 0x7fffffff, COUNT>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact, &cn.cull_nohit, &cn.cull_beyond);
                                 else if (COUNT) node_step<PT_WAVE, 0x7fffffff>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth); // the one-level walk exists in the instrumented instance only
                                 PT_STASH_LEAF(0x7fffffff);
                             }
@@ -1206,8 +1207,8 @@ __global__ void __launch_bounds__(PT_WAVE, WAVES) pt_render_wave_kernel(const Pt
                       }
 #endif
                     } else if (cur >= 0) { // some stack of the wave is about to leave LDS (rare): per-lane fetch, overflow-aware pushes
-                        if (COUNT) cn.nodes += nodes4 ? 2 : 1;
-                        if (nodes4) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact);
+                        if (COUNT) cn.nodes += quad ? 2 : 1;
+                        if (quad) node4_step<PT_WAVE, PT_LDS_STACK>(nodes4, stack, ovf, o, inv, h.t, cur, sp, box_exact);
                         else if (COUNT) node_step<PT_WAVE, PT_LDS_STACK>(nodes, stack, ovf, o, inv, h.t, cur, sp, cn.depth);
                         if (cur < PT_DONE && pend == PT_DONE) {
                             pend = cur;
