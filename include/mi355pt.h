@@ -187,9 +187,9 @@ int pt_group_render(pt_group* g, const pt_camera* cam, int32_t width, int32_t he
 
 /* Tuning / test options (all have working defaults; none changes an image):
  *   "kernel" 2 (default, wavefront-scheduled) | 1 (lane per pixel);  "count" 0/1: instrumented kernel that fills pt_stats;
- *   "leaf_size", "max_bvh_depth": BVH builder, next pt_upload_scene;  "bvh_builder" 3 (default: by triangle count - 0 up to 2 M
- *   triangles, 2 beyond) | 0 (binned SAH on the host: the tree that walks fastest) | 1 (linear BVH built on the device, csrc/pt_lbvh.hip:
- *   6x faster to build, 1.25x slower to walk) | 2 (PLOC on the device: 3x faster to build, 1.08x slower to walk; "ploc_radius" 16; a tree
+ *   "leaf_size", "max_bvh_depth": BVH builder, next pt_upload_scene;  "bvh_builder" 3 (default: by triangle count - 0 up to 64 M
+ *   triangles, 2 beyond) | 0 (binned SAH on all host threads: the tree that walks fastest, 0.9 M triangles in 58-83 ms) | 1 (linear BVH built on
+ *   the device, csrc/pt_lbvh.hip: 50 ms, 1.4x slower to walk) | 2 (PLOC on the device: 88 ms, 1.04-1.25x slower to walk; "ploc_radius" 16; a tree
  *   deeper than max_bvh_depth falls back to 0);  "blocks_per_cu", "slots_per_wave": launch geometry;
  *   "schedule" 1 (default: cost pre-pass + cost-ordered queue, from 4 x prepass_spp samples per pixel) | 0 (chunks only);
  *   "prepass_spp" (0 = automatic: 8, or 16 when a tier plan is prepared), "cost_radius" (2: the cost of a pixel - the time its pre-pass

@@ -16,7 +16,7 @@
 #include "pt_launch.h"
 #include "pt_tiers.h"
 
-#define PT_AUTO_PLOC_TRIS 2000000
+#define PT_AUTO_PLOC_TRIS 64000000 // builder 3: the device PLOC builder beyond this many triangles (see pt_upload_scene)
 
 namespace {
 std::string g_create_error;
@@ -417,8 +417,10 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
     // ---- BVH (replaces owlGroupBuildAccel, application.cpp:135-139) ----
     auto t0 = std::chrono::steady_clock::now();
     const int leaf_sz = std::max(1, std::min(7, c->leaf_size));
-    // builder 3 = automatic: the host SAH tree walks fastest (C4: 561 ms against 606 for PLOC and 697 for the Karras tree) and is built
-    // in 0.3 s for 0.9 M triangles; beyond PT_AUTO_PLOC_TRIS triangles the device PLOC builder takes over (3x faster to build)
+    // builder 3 = automatic: the host SAH tree walks fastest (C4: 478 ms against 606 for PLOC and 697 for the Karras tree) and, since the
+    // builder runs on all host threads (round 4), is built as fast as the device PLOC tree comes down and is laid out: 0.9 M triangles 58-83 ms
+    // against 88, 4 M triangles 350 against 360 ms (and walks 4 % faster there) - PLOC only takes over where the host builder's memory would
+    // become the limit (PT_AUTO_PLOC_TRIS)
     const int builder = c->bvh_builder == 3 ? (n_tris > (size_t)PT_AUTO_PLOC_TRIS ? 2 : 0) : c->bvh_builder;
     if (builder == 2 && !c->host_only && n_tris > (size_t)leaf_sz) {
         // device PLOC (pt_lbvh.hip): the hierarchy comes down, the host lays it out (pt_bvh_from_hierarchy)
