@@ -94,8 +94,9 @@ __device__ __forceinline__ void node4_step(const PtNode4* __restrict__ nodes4, u
     // |o/d| 2^-24, i.e. the plane seems displaced by |o| 2^-24 in space: rays start on surfaces or at the camera, the boxes are padded by
     // 1e-5 x the scene extent, and the host launches the instances with the subtracting form (`exact`) for a camera farther than 42
     // extents from the origin (pt_api.cpp) - the test stays conservative with respect to every hit the triangle test can report, and
-    // the triangle test decides the image.  inf - inf (a direction component of exactly 0) gives NaN, which min / max ignore: that axis
-    // then never culls.  (Both forms behind a run-time switch in ONE instance cost 4 %: C4 486 -> 508 ms, profiles/r04_notes.md.)
+    // the triangle test decides the image.  The reciprocals are finite (ray_inv clamps them: a direction component of exactly 0 would
+    // otherwise give -inf or NaN here depending on the signs of plane and origin, and cull boxes the ray runs through).
+    // (Both forms behind a run-time switch in ONE instance cost 4 %: C4 486 -> 508 ms, profiles/r04_notes.md.)
     const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const float nx = -(o.x * inv.x), ny = -(o.y * inv.y), nz = -(o.z * inv.z);
     const f32x2 nox = {nx, nx}, noy = {ny, ny}, noz = {nz, nz};

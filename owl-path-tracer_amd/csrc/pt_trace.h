@@ -77,17 +77,26 @@ __device__ __forceinline__ bool box_test_fma(float bminx, float bminy, float bmi
 // (ten instructions each, three per ray, in the refill step every lane runs through).  A slab distance is then off by a relative
 // 2^-23 at most, i.e. a plane seems displaced by < 1.2e-7 x its distance from the ray origin - every box is padded by 1e-5 x the scene
 // extent (pt_bvh.cpp), eighty times that - so the test stays conservative with respect to every hit the triangle test can report,
-// and the triangle test itself (which decides t, u, v and the image) does not use it.  0 -> inf like the division.
+// and the triangle test itself (which decides t, u, v and the image) does not use it.
+// The reciprocal is CLAMPED to +-PT_INV_MAX: a direction component of exactly 0 (a horizontal camera's middle row: the jitter is absorbed
+// when `lower_left + v * vertical - origin` is formed, ~3e-5 of that row's samples; mirror bounces keep it) must not become inf in the
+// fma form of the slab test - fma(plane, inf, -(o * inf)) is NaN only where plane and o have the same sign and -inf otherwise, which
+// culled every box that straddles 0 on that axis, the root included (3 pixels of C2's 262 144 differed from the oracle at 256 spp:
+// profiles/r04_notes.md 7; found by the whole-frame comparison at full spp).  With a finite reciprocal both forms give
+// (plane - o) * 1e18 up to rounding: no constraint from a slab the origin is inside of, a cull for one it is outside of, and a ray that
+// runs within 1e-8 of a box face - which is padded, so >= 1e-5 extents away from every triangle of the box - may be culled either way.
 #ifndef PT_FAST_RAY_INV
 #define PT_FAST_RAY_INV 1
 #endif
+#define PT_INV_MAX 1e18f
 __device__ __forceinline__ v3 ray_inv(v3 d)
 {
 #if PT_FAST_RAY_INV
-    return V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float x = __builtin_amdgcn_rcpf(d.x), y = __builtin_amdgcn_rcpf(d.y), z = __builtin_amdgcn_rcpf(d.z);
 #else
-    return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float x = 1.0f / d.x, y = 1.0f / d.y, z = 1.0f / d.z;
 #endif
+    return V(__builtin_amdgcn_fmed3f(x, -PT_INV_MAX, PT_INV_MAX), __builtin_amdgcn_fmed3f(y, -PT_INV_MAX, PT_INV_MAX), __builtin_amdgcn_fmed3f(z, -PT_INV_MAX, PT_INV_MAX));
 }
 
 // Moeller-Trumbore, two-sided, kTMin < t; ties in t go to the lower global id (order independent result).

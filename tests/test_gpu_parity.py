@@ -617,6 +617,13 @@ def test_c2_cornell_full_size(gpu, orc, cornell):
     assert np.isfinite(a).all() and a.min() >= 0
     S = orc.Scene(cornell["flat"])
     _subset_check(a, S, orc, cam, orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 256, 16, 1500, 3)
+    # the two middle rows in full: the camera looks horizontally, so ~3e-5 of these rows' camera rays have a direction component of EXACTLY 0
+    # (the jitter is absorbed when the direction is formed) - the case that the fma form of the slab test got wrong with an infinite
+    # reciprocal (round 4: three pixels of this frame; ray_inv in csrc/pt_trace.h)
+    ids = np.arange((H // 2 - 1) * W, (H // 2 + 1) * W, dtype=np.uint32)
+    sub = np.zeros((H, W, 3), np.float32)
+    S.render(_ocam(orc, cam), orc.make_env(color=(1, 1, 1), intensity=0.0), W, H, 256, 16, pixel_list=ids, out=sub)
+    assert_bitwise(a[H // 2 - 1:H // 2 + 1], sub[H // 2 - 1:H // 2 + 1], "C2: the two middle rows at full spp (axis-parallel camera rays)")
     print("C2 kernel_ms=%.1f Msamples/s=%.1f vgprs=%d" % (st["kernel_ms"], W * H * 256 / st["kernel_ms"] / 1e3, st["vgprs"]))
 
 
@@ -744,6 +751,82 @@ def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 4096, 16, 160, 6)
     _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C5")
     print("C5 (counted) kernel_ms=%.1f Msamples/s=%.1f rays/sample=%.2f" % (st["kernel_ms"], W * H * 4096 / st["kernel_ms"] / 1e3, st["rays"] / st["samples"]))
+
+
+def _host_threads():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+@pytest.mark.skipif(os.environ.get("PT_FULL_FRAME_PARITY") != "1", reason="opt-in (PT_FULL_FRAME_PARITY=1): ~7 minutes of oracle time on 16 threads")
+def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
+    """EVERY pixel of C2, C3 and C4 at the configs' full sample counts (and every 8th row of C5 at 4096 spp) against the oracle, bit for
+    bit - what the regular suite can only afford on pixel subsets (full spp) or at 4-32 spp (whole frames).  Writes one record per config
+    to gpurun_out/full_frame_parity.json (committed as profiles/rNN_full_frame_parity.json after a run)."""
+    import json, time, zlib
+    assets = os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets")
+    out_path = os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "full_frame_parity.json")
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    threads = _host_threads()
+    records = []
+
+    def check(name, S, cam, env_gpu, env_orc, W, H, spp, rows=None):
+        got, _ = gpu.render(cam, W, H, spp, 16)
+        ms = gpu.stats()["kernel_ms"]
+        t0 = time.perf_counter()
+        if rows is None:
+            want, _, _ = S.render(_ocam(orc, cam), env_orc, W, H, spp, 16, threads=threads)
+            a, b = got, want
+        else:  # pixel ids count from the bottom row (B.shard_pixels convention); framebuffer row 0 is the top
+            ids = (np.asarray(rows, np.uint32)[:, None] * np.uint32(W) + np.arange(W, dtype=np.uint32)[None, :]).ravel()
+            sub = np.zeros((H, W, 3), np.float32)
+            S.render(_ocam(orc, cam), env_orc, W, H, spp, 16, threads=threads, pixel_list=ids, out=sub)
+            ys = H - 1 - np.asarray(rows)
+            a, b = got[ys], sub[ys]
+        dt = time.perf_counter() - t0
+        same = bool((bits(a) == bits(b)).all())
+        rec = {"config": name, "width": W, "height": H, "spp": spp, "pixels_compared": int(a.shape[0] * a.shape[1]), "bit_identical": same,
+               "crc32_gpu": zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF, "crc32_oracle": zlib.crc32(np.ascontiguousarray(b).tobytes()) & 0xFFFFFFFF,
+               "gpu_kernel_ms": round(ms, 2), "oracle_s": round(dt, 1), "oracle_threads": threads}
+        records.append(rec)
+        with open(out_path, "w") as f:
+            json.dump(records, f, indent=1)
+        print(rec, flush=True)
+        assert same, "%s: whole frame at full spp differs from the oracle" % name
+
+    # C2
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
+    check("C2 cornell-box 512x512x256", orc.Scene(cornell["flat"]), _cam(cornell, 512, 512), None, orc.make_env(color=(1, 1, 1), intensity=0.0), 512, 512, 256)
+    # C3
+    _, mats = scene_io.parse_scene(os.path.join(assets, "mitsuba.json"))
+    ents = scene_io.build_entities(procedural.mitsuba_standin(), mats)
+    env = dict(use_auto=True, intensity=1.0)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
+    check("C3 mitsuba stand-in 1024x1024x512", orc.Scene(scene_io.flatten_scene(ents, mats)), mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, 1024, 1024), None,
+          orc.make_env(**env), 1024, 1024, 512)
+    # C4
+    _, mats = scene_io.parse_scene(os.path.join(assets, "dragon.json"))
+    ents = scene_io.build_entities(procedural.dragon_standin(), mats)
+    env = dict(color=(1, 1, 1), intensity=0.0)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
+    check("C4 dragon stand-in 1920x1080x1024", orc.Scene(scene_io.flatten_scene(ents, mats)), mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, 1920, 1080), None,
+          orc.make_env(**env), 1920, 1080, 1024)
+    # C5: every 8th row
+    _, mats = scene_io.parse_scene(os.path.join(assets, "car.json"))
+    ents = scene_io.build_entities(procedural.car_standin(), mats)
+    gi = [n for n, _, _ in mats].index("Ground")
+    tex = scene_io.checker_texture(256, 256, 16)
+    envmap = procedural.rgbe_to_ldr_rgba8(procedural.synthetic_sky_rgbe(2048, 1024))
+    env = dict(use_map=True, intensity=1.0, env_map=envmap)
+    gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
+    check("C5 car stand-in 1920x1080x4096, every 8th row", orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex})), mkcam([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, 1920, 1080), None,
+          orc.make_env(**env), 1920, 1080, 4096, rows=list(range(3, 1080, 8)))
 
 
 def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
