@@ -775,6 +775,14 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     threads = _host_threads()
     records = []
+    DEFAULTS = {"groups": 1, "whole": -1, "fallback": 0, "box_exact": -1, "kernel": 2, "schedule": 1, "count": 0, "quad": 1, "express_permille": -1, "chunk_spp": 64}
+    variants = [("group walk for every traversal phase (groups=2)", [("groups", 2)]), ("no group walk (groups=0)", [("groups", 0)]),
+                ("tier plan forced (whole=1)", [("whole", 1)]), ("no tier plan (whole=0)", [("whole", 0)]),
+                ("50 per mille express pixels", [("whole", 0), ("express_permille", 50)]),
+                ("140-VGPR fallback instance", [("fallback", 1)]), ("subtracting slab form (box_exact=1)", [("box_exact", 1)]),
+                ("schedule 0, 16-sample chunks", [("schedule", 0), ("chunk_spp", 16)]),
+                ("instrumented instance (count=1)", [("count", 1)]), ("instrumented instance, one-level walk (count=1, quad=0, groups=0)", [("count", 1), ("quad", 0), ("groups", 0)]),
+                ("lane-per-pixel kernel", [("kernel", 1)])]
 
     def check(name, S, cam, env_gpu, env_orc, W, H, spp, rows=None):
         got, _ = gpu.render(cam, W, H, spp, 16)
@@ -799,6 +807,22 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
             json.dump(records, f, indent=1)
         print(rec, flush=True)
         assert same, "%s: whole frame at full spp differs from the oracle" % name
+        # every other way this library can render the same frame (other walks, instances and schedules) - against the same oracle frame
+        for label, opts in variants if rows is None else ():
+            for k, v in opts:
+                gpu.set_option(k, v)
+            try:
+                alt, _ = gpu.render(cam, W, H, spp, 16)
+                alt_ms = gpu.stats()["kernel_ms"]
+            finally:
+                for k, _ in opts:
+                    gpu.set_option(k, DEFAULTS[k])
+            ok = bool((bits(alt) == bits(want)).all())
+            rec.setdefault("variants", []).append({"options": label, "bit_identical": ok, "gpu_kernel_ms": round(alt_ms, 2)})
+            with open(out_path, "w") as f:
+                json.dump(records, f, indent=1)
+            print("   ", label, ok, "%.1f ms" % alt_ms, flush=True)
+            assert ok, "%s with %s: whole frame at full spp differs from the oracle" % (name, label)
 
     # C2
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
