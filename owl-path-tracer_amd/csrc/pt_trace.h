@@ -88,7 +88,9 @@ __device__ __forceinline__ bool box_test_fma(float bminx, float bminy, float bmi
 #ifndef PT_FAST_RAY_INV
 #define PT_FAST_RAY_INV 1
 #endif
-#define PT_INV_MAX 1e18f
+#ifndef PT_INV_MAX
+#define PT_INV_MAX 1e18f // (tests build a variant with infinity here to see the regression tests fail)
+#endif
 __device__ __forceinline__ v3 ray_inv(v3 d)
 {
 #if PT_FAST_RAY_INV

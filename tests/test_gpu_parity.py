@@ -545,6 +545,45 @@ def test_slab_test_forms_and_far_camera(gpu, orc, cornell):
     assert_bitwise(got, want, "camera 3000 units away (automatic: subtracting form)")
 
 
+def test_axis_parallel_cameras(gpu, orc, cornell):
+    """Cameras that look exactly along +-x, +-y, +-z from points whose coordinates are not 0: in the middle row AND the middle column the
+    jitter is absorbed when the direction is formed, so those camera rays have one (at the centre: two) direction components of exactly 0 -
+    1/d = inf.  Both slab forms, the group walk and the lane-per-pixel kernel must give the oracle's image (the fma form culled boxes that
+    straddle 0 on such an axis before ray_inv clamped the reciprocal: csrc/pt_trace.h)."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.35))
+    S = orc.Scene(cornell["flat"])
+    oenv = orc.make_env(color=(1, 1, 1), intensity=0.35)
+    V = np.asarray(cornell["flat"]["positions"], np.float32).reshape(-1, 3)
+    lo, hi = V.min(0), V.max(0)
+    centre = ((lo + hi) * 0.5 + np.array([0.25, 0.125, 0.5], np.float32) * (hi - lo) * 0.25).astype(np.float32)
+    # a narrow field of view makes the window wide: |jitter| / H * 2 tan(fov / 2) < ulp(origin) / 2 holds for ~3e-4 of the samples of the two
+    # middle rows / columns at 0.5 degrees, i.e. a handful of such rays per camera at 32 x 32 x 512 (with infinity for the clamp,
+    # `make variant NAME=noclamp FLAGS='-DPT_INV_MAX=__builtin_inff\(\)'`, every camera of this test fails)
+    W = H = 32
+    n_zero = 0
+    try:
+        for axis in range(3):
+            for sign in (-1.0, 1.0):
+                frm = centre.copy()
+                frm[axis] += sign * 0.45 * (hi - lo)[axis]  # inside the scene's box, looking through its centre
+                up = [0.0, 0.0, 0.0]
+                up[(axis + 1) % 3] = 1.0
+                cam = mkcam([float(x) for x in frm], [float(x) for x in centre], up, 0.5, W, H)
+                want, _, _ = S.render(_ocam(orc, cam), oenv, W, H, 512, 8)
+                for opts in ((), (("box_exact", 1),), (("groups", 2),), (("kernel", 1),)):
+                    for k, v in opts:
+                        gpu.set_option(k, v)
+                    got, _ = gpu.render(cam, W, H, 512, 8)
+                    for k, _ in opts:
+                        gpu.set_option(k, {"box_exact": -1, "groups": 1, "kernel": 2}[k])
+                    assert_bitwise(got, want, "camera along %s%s, options %s" % ("-+"[sign > 0], "xyz"[axis], opts))
+                n_zero += 1
+    finally:
+        for k, v in (("box_exact", -1), ("groups", 1), ("kernel", 2)):
+            gpu.set_option(k, v)
+    assert n_zero == 6
+
+
 def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
     """option kernel=1 (persistent lane-per-pixel scheduler) must produce the same bits as the default wavefront scheduler."""
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
