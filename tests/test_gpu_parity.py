@@ -803,10 +803,11 @@ def _host_threads():
     return max(1, n)
 
 
-@pytest.mark.skipif(os.environ.get("PT_FULL_FRAME_PARITY") != "1", reason="opt-in (PT_FULL_FRAME_PARITY=1): ~7 minutes of oracle time on 16 threads")
+@pytest.mark.skipif(os.environ.get("PT_FULL_FRAME_PARITY") != "1", reason="opt-in (PT_FULL_FRAME_PARITY=1): ~8 minutes of oracle time on 16 threads")
 def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
-    """EVERY pixel of C2, C3 and C4 at the configs' full sample counts (and every 8th row of C5 at 4096 spp) against the oracle, bit for
-    bit - what the regular suite can only afford on pixel subsets (full spp) or at 4-32 spp (whole frames).  Writes one record per config
+    """EVERY pixel of C2, C3 and C4 at the configs' full sample counts (C3 also under the five variants of the material sweep; C5: every 8th
+    row at 4096 spp and every pixel for its first 256 spp) against the oracle, bit for bit - what the regular suite can only afford on
+    pixel subsets (full spp) or at 4-32 spp (whole frames) - and C2 / C3 / C4 again through every other render path of the library.  Writes one record per config
     to gpurun_out/full_frame_parity.json (committed as profiles/rNN_full_frame_parity.json after a run)."""
     import json, time, zlib
     assets = os.path.join(os.path.dirname(B.HEADER_PATH), "..", "assets")
@@ -822,6 +823,9 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
                 ("schedule 0, 16-sample chunks", [("schedule", 0), ("chunk_spp", 16)]),
                 ("instrumented instance (count=1)", [("count", 1)]), ("instrumented instance, one-level walk (count=1, quad=0, groups=0)", [("count", 1), ("quad", 0), ("groups", 0)]),
                 ("lane-per-pixel kernel", [("kernel", 1)])]
+
+    def active_variants():
+        return variants
 
     def check(name, S, cam, env_gpu, env_orc, W, H, spp, rows=None):
         got, _ = gpu.render(cam, W, H, spp, 16)
@@ -847,7 +851,7 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
         print(rec, flush=True)
         assert same, "%s: whole frame at full spp differs from the oracle" % name
         # every other way this library can render the same frame (other walks, instances and schedules) - against the same oracle frame
-        for label, opts in variants if rows is None else ():
+        for label, opts in active_variants() if rows is None else ():
             for k, v in opts:
                 gpu.set_option(k, v)
             try:
@@ -871,8 +875,23 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
     ents = scene_io.build_entities(procedural.mitsuba_standin(), mats)
     env = dict(use_auto=True, intensity=1.0)
     gpu.upload_scene(ents, [m for _, m, _ in mats], env=B.make_env(**env))
-    check("C3 mitsuba stand-in 1024x1024x512", orc.Scene(scene_io.flatten_scene(ents, mats)), mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, 1024, 1024), None,
-          orc.make_env(**env), 1024, 1024, 512)
+    S3 = orc.Scene(scene_io.flatten_scene(ents, mats))
+    cam3 = mkcam([4, 2.5, 0], [0, 0.75, 0], [0, 1, 0], 50, 1024, 1024)
+    check("C3 mitsuba stand-in 1024x1024x512", S3, cam3, None, orc.make_env(**env), 1024, 1024, 512)
+    # C3 under the material sweep (test_c3_material_sweep_full_size: subsets only): every pixel at full spp, all five variants
+    base = np.stack([m for _, m, _ in mats]).astype(np.float32)
+    all_variants, variants = variants, []
+    for label, edits in (("metallic 1, roughness .3", {4: 1.0, 7: 0.3}), ("clearcoat 1", {11: 1.0}), ("transmission .5, roughness .3", {14: 0.5, 15: 0.3}), ("sheen 1", {9: 1.0}),
+                         ("four lobes: metallic .3, clearcoat 1, transmission .5, sheen .5", {4: 0.3, 11: 1.0, 14: 0.5, 9: 0.5})):
+        mm = base.copy()
+        for i, (n, _, _) in enumerate(mats):
+            if n != "ground":
+                for f, v in edits.items():
+                    mm[i, f] = v
+        gpu.set_materials(mm)
+        S3.set_materials(mm)
+        check("C3 sweep: " + label, S3, cam3, None, orc.make_env(**env), 1024, 1024, 512)
+    variants = all_variants
     # C4
     _, mats = scene_io.parse_scene(os.path.join(assets, "dragon.json"))
     ents = scene_io.build_entities(procedural.dragon_standin(), mats)
@@ -888,8 +907,11 @@ def test_whole_frames_at_full_spp(gpu, orc, cornell, scene_io, procedural):
     envmap = procedural.rgbe_to_ldr_rgba8(procedural.synthetic_sky_rgbe(2048, 1024))
     env = dict(use_map=True, intensity=1.0, env_map=envmap)
     gpu.upload_scene(ents, [m for _, m, _ in mats], textures=[tex], mesh_textures=[0 if mid == gi else -1 for _, mid in ents], env=B.make_env(**env))
-    check("C5 car stand-in 1920x1080x4096, every 8th row", orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex})), mkcam([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, 1920, 1080), None,
-          orc.make_env(**env), 1920, 1080, 4096, rows=list(range(3, 1080, 8)))
+    S5 = orc.Scene(scene_io.flatten_scene(ents, mats, {gi: tex}))
+    cam5 = mkcam([0, 2, 5], [0, 0.5, 0], [0, 1, 0], 45, 1920, 1080)
+    check("C5 car stand-in 1920x1080x4096, every 8th row", S5, cam5, None, orc.make_env(**env), 1920, 1080, 4096, rows=list(range(3, 1080, 8)))
+    variants = []
+    check("C5 car stand-in 1920x1080, every pixel, the first 256 of 4096 spp", S5, cam5, None, orc.make_env(**env), 1920, 1080, 256)
 
 
 def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
