@@ -584,6 +584,45 @@ def test_axis_parallel_cameras(gpu, orc, cornell):
     assert n_zero == 6
 
 
+def test_nan_retry_path(gpu, orc, cornell):
+    """device.cu:196-201: a BSDF value that is NaN or infinite sends the path back to the same hit with fresh draws.  No config and no
+    finite material reaches that branch (nan_retries == 0 in every census), so it is driven here with base colours of NaN, infinity and
+    3e38 (which overflows on the way: infinite throughput, NaN pixels): millions of retries per frame, the 64-retry safety net, NaN
+    propagation into the frame - image, NaN pattern and work counters must be the oracle's, in every kernel."""
+    _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.5))
+    S = orc.Scene(cornell["flat"])
+    oenv = orc.make_env(color=(1, 1, 1), intensity=0.5)
+    base = np.stack(_mats(cornell)).astype(np.float32)
+    W = H = 64
+    cam = _cam(cornell, W, H)
+    total = 0
+    try:
+        for who, val in ((0, np.nan), (1, np.inf), (3, 3e38), (0, 3e38), (3, np.nan)):
+            mm = base.copy()
+            mm[who, 0] = val
+            mm[who, 1] = val
+            gpu.set_materials(mm)
+            S.set_materials(mm)
+            want, _, cnt = S.render(_ocam(orc, cam), oenv, W, H, 32, 16, want_counters=True)
+            total += cnt["nan_retries"]
+            for opts in ((("count", 1),), (), (("groups", 2),), (("kernel", 1),)):
+                for k, v in opts:
+                    gpu.set_option(k, v)
+                got, _ = gpu.render(cam, W, H, 32, 16)
+                st = gpu.stats()
+                for k, _ in opts:
+                    gpu.set_option(k, {"count": 0, "groups": 1, "kernel": 2}[k])
+                assert_bitwise(got, want, "base colour %r on material %d, options %s" % (val, who, opts))
+                if opts and opts[0][0] == "count":
+                    for k in ("samples", "rays", "scatters", "nan_retries"):
+                        assert st[k] == cnt[k], (k, st[k], cnt[k])
+    finally:
+        gpu.set_materials(base)
+        for k, v in (("count", 0), ("groups", 1), ("kernel", 2)):
+            gpu.set_option(k, v)
+    assert total > 1_000_000  # the branch was really taken
+
+
 def test_lane_per_pixel_variant_bitwise(gpu, orc, cornell):
     """option kernel=1 (persistent lane-per-pixel scheduler) must produce the same bits as the default wavefront scheduler."""
     _upload(gpu, cornell, env=B.make_env(color=(1, 1, 1), intensity=0.0))
