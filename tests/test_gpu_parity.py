@@ -975,6 +975,74 @@ def test_one_quad_scene_leaf_root(gpu, orc, scene_io):
     gpu.set_option("kernel", 2)
 
 
+def test_texture_lookup_edge_cases(gpu, orc, scene_io):
+    """Texture coordinates outside [0, 1] (negative, > 1, exactly 0 and 1 at the corners), textures that are neither square nor powers of
+    two, and a 1 x 1 texture: the nearest-texel lookup (device.cu:75-94 / tex2D with the reference's wrap mode) against the oracle on
+    quads whose texcoords run from -1.25 to 2.5."""
+    def quad(z, tc):
+        return dict(vertices=np.array([[-1, 0, z - 1], [1, 0, z - 1], [1, 0, z + 1], [-1, 0, z + 1]], np.float32), normals=np.array([[0, 1, 0]] * 4, np.float32),
+                    texcoords=np.asarray(tc, np.float32), indices=np.array([[0, 1, 2], [0, 2, 3]], np.int32))
+    mat = np.zeros((3, 17), np.float32)
+    mat[:, :3] = (0.7, 0.6, 0.5); mat[:, 5] = 0.5; mat[:, 7] = 0.6; mat[:, 13] = 1.45
+    ents = [(quad(-2.2, [[-1.25, -0.5], [2.5, -0.5], [2.5, 1.75], [-1.25, 1.75]]), 0), (quad(0.0, [[0, 0], [1, 0], [1, 1], [0, 1]]), 1),
+            (quad(2.2, [[0.3, 0.3], [0.4, 0.3], [0.4, 0.4], [0.3, 0.4]]), 2)]
+    rng = np.random.default_rng(11)
+    def tex(w, h):
+        px = rng.integers(0, 256, (h, w, 3)).astype(np.uint32)
+        return (px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | (0xFF << 24)).astype(np.uint32)
+    texs = [tex(5, 3), tex(7, 13), tex(1, 1)]
+    gpu.upload_scene(ents, mat, textures=texs, mesh_textures=[0, 1, 2], env=B.make_env(use_auto=True, intensity=1.0))
+    W, H = 160, 96
+    cam = mkcam([0, 2.5, 5.5], [0, 0, 0], [0, 1, 0], 50, W, H)
+    S = orc.Scene(scene_io.flatten_scene(ents, [("a", mat[0], ""), ("b", mat[1], ""), ("c", mat[2], "")], {0: texs[0], 1: texs[1], 2: texs[2]}))
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 24, 6)
+    assert len(np.unique(want.reshape(-1, 3), axis=0)) > 1000
+    for k in (2, 1):
+        gpu.set_option("kernel", k)
+        got, _ = gpu.render(cam, W, H, 24, 6)
+        assert_bitwise(got, want, "textured quads, kernel %d" % k)
+    gpu.set_option("kernel", 2)
+
+
+def test_degenerate_and_coincident_geometry(gpu, orc, scene_io):
+    """Coincident triangles (the same quad twice, with different materials: equal t - the lower global triangle id must win in every walk),
+    zero-area triangles (two or three equal vertices: det = 0, never a hit), 200 copies of one small triangle (every centroid equal: the SAH
+    builder's fallback split) and a needle a million times longer than wide - all three builders, both kernels, the group walk."""
+    def mesh(v, idx):
+        v = np.asarray(v, np.float32)
+        return dict(vertices=v, normals=np.tile(np.array([[0, 1, 0]], np.float32), (len(v), 1)), texcoords=np.zeros((len(v), 2), np.float32), indices=np.asarray(idx, np.int32))
+    q = [[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]]
+    mat = np.zeros((4, 17), np.float32)
+    mat[:, 5] = 0.5; mat[:, 7] = 0.6; mat[:, 13] = 1.45
+    mat[0, :3] = (0.8, 0.1, 0.1); mat[1, :3] = (0.1, 0.8, 0.1); mat[2, :3] = (0.1, 0.1, 0.8); mat[3, :3] = (0.7, 0.7, 0.2)
+    small = [[0.2, 0.3, 0.2], [0.4, 0.3, 0.2], [0.3, 0.3, 0.4]]
+    ents = [(mesh(q, [[0, 1, 2], [0, 2, 3]]), 0), (mesh(q, [[0, 1, 2], [0, 2, 3]]), 1),                       # coincident quads
+            (mesh([[0, 0.5, 0], [0, 0.5, 0], [1, 0.5, 0], [0.5, 0.5, 0.5]], [[0, 1, 2], [3, 3, 3], [0, 2, 2]]), 2),  # zero-area triangles
+            (mesh(small * 200, np.arange(600).reshape(200, 3)), 3),                                             # 200 identical triangles
+            (mesh([[-0.9, 0.2, -0.5], [0.9, 0.2000009, -0.5], [0.9, 0.2, -0.4999991]], [[0, 1, 2]]), 2)]          # a needle
+    names = [("r", mat[0], ""), ("g", mat[1], ""), ("b", mat[2], ""), ("y", mat[3], "")]
+    W, H = 128, 96
+    cam = mkcam([0.4, 1.8, 2.6], [0, 0.1, 0], [0, 1, 0], 45, W, H)
+    S = orc.Scene(scene_io.flatten_scene(ents, names))
+    want, _, _ = S.render(_ocam(orc, cam), orc.make_env(use_auto=True, intensity=1.0), W, H, 24, 8)
+    assert want[H // 2 + 10, W // 2, 0] > want[H // 2 + 10, W // 2, 1]  # the first (red) of the coincident quads wins
+    try:
+        for builder in (0, 1, 2):
+            gpu.set_option("bvh_builder", builder)
+            gpu.upload_scene(ents, mat, env=B.make_env(use_auto=True, intensity=1.0))
+            for opts in ((), (("groups", 2),), (("kernel", 1),), (("count", 1), ("quad", 0), ("groups", 0))):
+                for k, v in opts:
+                    gpu.set_option(k, v)
+                got, _ = gpu.render(cam, W, H, 24, 8)
+                for k, _ in opts:
+                    gpu.set_option(k, {"groups": 1, "kernel": 2, "count": 0, "quad": 1}[k])
+                assert_bitwise(got, want, "degenerate scene, builder %d, options %s" % (builder, opts))
+    finally:
+        gpu.set_option("bvh_builder", 3)
+        for k, v in (("groups", 1), ("kernel", 2), ("count", 0), ("quad", 1)):
+            gpu.set_option(k, v)
+
+
 def test_group_walk_bitwise(gpu, orc, cornell, scene_io, procedural):
     """Round 3: the group walk (eight lanes per ray over oct nodes, pt_kernel.hip traverse_groups) is what a SPARSE wave traverses
     with.  Closest hit does not depend on the visiting order, so forcing it on for every ray (groups = 2), leaving it to the sparse
