@@ -264,7 +264,7 @@ def main():
     if rank == 0:
         if args.write_golden:
             with open(GOLDEN_CRC, "w") as f:
-                json.dump({"workload": "C4 stand-in 1920x1080x1024spp depth 16 (bench.py)", "crc32_float3_frame": crc,
+                json.dump({"workload": "C4 stand-in 1920x1080x1024spp depth 16 (bench.py)", "crc32_float3_frame": crc, "provenance": "bench.py --write-golden (re-run the opt-in whole-frame oracle comparison to tie it to the oracle again)",
                            "mean": float(np.mean(frame.rgb, dtype=np.float64))}, f)
         frame_check = "no golden checksum"
         if os.path.exists(GOLDEN_CRC):

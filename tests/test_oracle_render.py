@@ -189,3 +189,17 @@ def test_furnace_against_reference_rendered_images(orc, scene_io, procedural, ke
     cam = orc.to_camera_data([3, 1, 0], [0, 1, 0], [0, 1, 0], 50, F.W, F.H)
     _, rgba, _ = S.render(cam, orc.make_env(color=(1, 1, 1), intensity=1), F.W, F.H, F.SPP, F.DEPTH, want_rgba8=True)
     F.check(key, rgba)
+
+
+def test_c4_golden_crc_is_the_oracles():
+    """The checksum bench.py asserts after its timed loop (tests/golden/c4_frame_crc.json) was first written by bench.py itself; since round 4
+    it is tied to the oracle: the whole C4 frame at full spp rendered by the ORACLE on the GPU box's host cores has the same crc32
+    (recorded by the opt-in GPU test test_whole_frames_at_full_spp in profiles/r04_full_frame_parity.json)."""
+    import json
+    root = os.path.join(os.path.dirname(__file__), "..")
+    golden = json.load(open(os.path.join(root, "tests", "golden", "c4_frame_crc.json")))["crc32_float3_frame"]
+    recs = json.load(open(os.path.join(root, "profiles", "r04_full_frame_parity.json")))
+    c4 = [r for r in recs if r["config"].startswith("C4 ")]
+    assert len(c4) == 1 and c4[0]["pixels_compared"] == 1920 * 1080 and c4[0]["spp"] == 1024
+    assert c4[0]["bit_identical"] and c4[0]["crc32_oracle"] == golden == c4[0]["crc32_gpu"]
+    assert all(r["bit_identical"] and all(v["bit_identical"] for v in r.get("variants", [])) for r in recs)
