@@ -379,6 +379,15 @@ class Scene:
             raise RuntimeError("orc_render failed: %d" % rc)
         return rgb, rgba, (cnt.as_dict() if cnt is not None else None)
 
+    def trace_sample(self, cam, env, W, H, px, py, sample, max_depth, use_bvh=True, max_rows=256):
+        """Per-bounce log of one sample of one pixel: (rows, 32) float32, layout in pt_oracle.c (ORC_LOG_FLOATS)."""
+        log = np.zeros((max_rows, 32), np.float32)
+        f = lib().orc_trace_sample
+        f.restype = C.c_int
+        n = f(C.c_void_p(self.h), C.byref(cam), C.byref(env), C.c_int(W), C.c_int(H), C.c_int(px), C.c_int(py), C.c_int(sample), C.c_int(max_depth), C.c_int(int(use_bvh)),
+              log.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(max_rows))
+        return log[:n]
+
     def trace_pixel(self, cam, env, W, H, px, py, spp, max_depth, use_bvh=True):
         rgb = np.zeros((spp, 3), np.float32)
         st = np.zeros(spp, np.uint32)

@@ -964,6 +964,26 @@ orc_scene* orc_scene_create(const orc_scene_desc* d, int leaf_size)
     int n = d->n_tris;
     s->n_tris = n;
     s->gpos = (float*)xmemdup(d->positions, (size_t)n * 9 * 4);
+    /* Closest-hit definition, part 2: slivers are never hit.  A triangle whose height over its longest edge is below 1e-5
+       of that edge (4 A^2 <= 1e-10 L^4, evaluated in double) is replaced by a point: for such a needle Moeller-Trumbore's u, v, t are
+       rounding noise, it can report a "hit" far outside the triangle's bounding box, and whether a BVH walk ever tests the triangle for
+       that ray then depends on the visiting order - the minimum over all triangles would not be what any hierarchy computes. */
+    for (int i = 0; i < n; ++i) {
+        float* q = s->gpos + (size_t)i * 9;
+        double a[3], b[3], cc[3], la = 0.0, lb = 0.0, lc = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            a[k] = (double)q[3 + k] - (double)q[k];
+            b[k] = (double)q[6 + k] - (double)q[k];
+            cc[k] = (double)q[6 + k] - (double)q[3 + k];
+        }
+        for (int k = 0; k < 3; ++k) { la += a[k] * a[k]; lb += b[k] * b[k]; lc += cc[k] * cc[k]; }
+        double nx = a[1] * b[2] - a[2] * b[1], ny = a[2] * b[0] - a[0] * b[2], nz = a[0] * b[1] - a[1] * b[0];
+        double four_area2 = nx * nx + ny * ny + nz * nz;
+        double longest2 = la > lb ? (la > lc ? la : lc) : (lb > lc ? lb : lc);
+        if (!(four_area2 > 1e-10 * longest2 * longest2)) {
+            for (int k = 0; k < 3; ++k) q[3 + k] = q[6 + k] = q[k];
+        }
+    }
     s->nrm = (float*)xmemdup(d->normals, (size_t)n * 9 * 4);
     s->tc = (float*)xmemdup(d->texcoords, (size_t)n * 6 * 4);
     s->mat_idx = (int32_t*)xmemdup(d->material_index, (size_t)n * 4);
@@ -1140,6 +1160,21 @@ typedef struct render_ctx {
     int use_bvh;
 } render_ctx;
 
+/* Per-bounce log of ONE sample (orc_trace_sample): 32 floats per bounce - org 0-2, dir 3-5, hit flag 6, t u v 7-9, prim 10 (int bits),
+   material index 11 (int bits), rng state before sample_disney 12 (uint bits), local_wo 13-15, f 16-18, pdf 19, local_wi 20-22,
+   sampled lobe 23 (int bits), throughput after the bounce 24-26, rng state after the bounce 27 (uint bits), radiance 28-30, depth 31. */
+#define ORC_LOG_FLOATS 32
+static __thread float* g_log = NULL;
+static __thread int g_log_rows = 0, g_log_cap = 0;
+static float* log_row(void)
+{
+    if (!g_log || g_log_rows >= g_log_cap) return NULL;
+    float* r = g_log + (size_t)g_log_rows++ * ORC_LOG_FLOATS;
+    memset(r, 0, ORC_LOG_FLOATS * sizeof(float));
+    return r;
+}
+static float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
 static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_counters* cnt)
 {
     const orc_scene* s = rc->s;
@@ -1154,6 +1189,11 @@ static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_co
         /* owl::traceRay, device.cu:133 (closest hit over all triangles, two-sided) */
         int got = rc->use_bvh ? intersect_bvh(s, org, dir, T_MIN, T_MAX, &h, cnt) : intersect_brute(s, org, dir, T_MIN, T_MAX, &h, cnt);
         if (cnt) cnt->rays++;
+        float* lg = log_row();
+        if (lg) {
+            st3(lg, org); st3(lg + 3, dir); lg[6] = (float)got; lg[31] = (float)depth;
+            if (got) { lg[7] = h.t; lg[8] = h.u; lg[9] = h.v; lg[10] = bits_f((uint32_t)h.prim); }
+        }
 
         if (!got) { /* device.cu:136-148 */
             if (env->use_map && env->map.width > 0) {
@@ -1206,8 +1246,10 @@ static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_co
         v3 local_wo = to_local(T, B, v_n, wo);
         v3 local_wi = vs(0.0f);
         float pdf = 0.0f;
+        if (lg) { lg[11] = bits_f((uint32_t)mi); lg[12] = bits_f(*rng); st3(lg + 13, local_wo); }
         v3 f = sample_disney(&mat, local_wo, rng, &local_wi, &pdf, &sampled_lobe);
         v3 wi = to_world(T, B, v_n, local_wi);
+        if (lg) { st3(lg + 16, f); lg[19] = pdf; st3(lg + 20, local_wi); lg[23] = bits_f((uint32_t)sampled_lobe); lg[27] = bits_f(*rng); }
 
         if (pdf < 1e-5f) break; /* device.cu:193 */
 
@@ -1227,6 +1269,7 @@ static v3 trace_path(const render_ctx* rc, v3 org, v3 dir, uint32_t* rng, orc_co
         throughput = vmul(throughput, vdivs(vscale(f, aci), pdf));
         org = v_p;
         dir = wi;
+        if (lg) st3(lg + 24, throughput);
 
         /* device.cu:209-214: inverted, uncompensated Russian roulette */
         float beta_max = dm_max(throughput.x, dm_max(throughput.y, throughput.z));
@@ -1328,6 +1371,29 @@ int orc_render(const orc_scene* s, const orc_camera* cam, const orc_env* env, in
     pthread_mutex_destroy(&j.mu);
     if (counters) *counters = j.total;
     return 0;
+}
+
+/* Test infrastructure for bisecting a parity failure: the per-bounce log (see ORC_LOG_FLOATS) of sample `sample` of pixel (px, py).
+   Returns the number of rows written. */
+int orc_trace_sample(const orc_scene* s, const orc_camera* cam, const orc_env* env, int W, int H, int px, int py, int sample, int max_depth,
+                     int use_bvh, float* log, int max_rows)
+{
+    render_ctx rc;
+    rc.s = s; rc.env = env; rc.max_depth = max_depth; rc.use_bvh = use_bvh;
+    uint32_t rng = orc_rng_init((uint32_t)px, (uint32_t)py);
+    v3 origin = ld3(cam->origin), llc = ld3(cam->llc), hor = ld3(cam->horizontal), ver = ld3(cam->vertical);
+    int rows = 0;
+    for (int k = 0; k <= sample; ++k) {
+        float rx = rng_next(&rng);
+        float ry = rng_next(&rng);
+        float su = ((float)px + rx) / (float)W;
+        float sv = ((float)py + ry) / (float)H;
+        v3 d = vnormalize(vsub(vadd(vadd(llc, vscale(hor, su)), vscale(ver, sv)), origin));
+        if (k == sample) { g_log = log; g_log_rows = 0; g_log_cap = max_rows; }
+        trace_path(&rc, origin, d, &rng, NULL);
+        if (k == sample) { rows = g_log_rows; g_log = NULL; g_log_cap = 0; }
+    }
+    return rows;
 }
 
 int orc_trace_pixel(const orc_scene* s, const orc_camera* cam, const orc_env* env, int W, int H, int px, int py, int max_samples,

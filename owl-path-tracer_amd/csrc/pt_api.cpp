@@ -16,6 +16,25 @@
 #include "pt_launch.h"
 #include "pt_tiers.h"
 
+// Slivers are never hit (part of the closest-hit definition; the oracle applies the same rule in its own words): a triangle
+// whose height over its longest edge is below 1e-5 of that edge - |e1 x e2|^2 <= 1e-10 * max|e|^4, in double - is collapsed to its first
+// vertex for the BVH and the triangle test (det = 0: the Moeller-Trumbore test rejects it for every ray).  Why: for such a needle the
+// test's u, v, t are rounding noise and it reports "hits" far outside the triangle's bounding box, which a BVH walk does or does not see
+// depending on the order in which it visits the leaves (found by tests/test_gpu_fuzz.py, seed 794689: the oracle's walk and this library's
+// disagreed on one ray of 1.7e4 random scenes).  A height of < 100 ulp of the coordinates carries no geometry anyway.
+static inline void pt_collapse_sliver(float* p)
+{
+    const double e1[3] = {(double)p[3] - (double)p[0], (double)p[4] - (double)p[1], (double)p[5] - (double)p[2]};
+    const double e2[3] = {(double)p[6] - (double)p[0], (double)p[7] - (double)p[1], (double)p[8] - (double)p[2]};
+    const double e3[3] = {(double)p[6] - (double)p[3], (double)p[7] - (double)p[4], (double)p[8] - (double)p[5]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2], l3 = e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2];
+    const double L2 = l1 > l2 ? (l1 > l3 ? l1 : l3) : (l2 > l3 ? l2 : l3);
+    if (!(n2 > 1e-10 * L2 * L2)) { // also NaN / infinite vertices
+        for (int k = 3; k < 9; ++k) p[k] = p[k % 3];
+    }
+}
 #define PT_AUTO_PLOC_TRIS 64000000 // builder 3: the device PLOC builder beyond this many triangles (see pt_upload_scene)
 
 namespace {
@@ -401,6 +420,7 @@ int pt_upload_scene(pt_ctx* c, const pt_mesh* meshes, int32_t n_meshes, const fl
                     if (textured && (!ms.texcoords || vi >= ms.n_texcoords)) { bad.store(3 + 4ll * vi); return; }
                     std::memcpy(&pos[(g0 + t) * 9 + (size_t)k * 3], ms.vertices + (size_t)vi * 3, 12);
                 }
+                pt_collapse_sliver(&pos[(g0 + t) * 9]);
             }
         });
         if (const long long b = bad.load()) {

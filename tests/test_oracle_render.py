@@ -203,3 +203,33 @@ def test_c4_golden_crc_is_the_oracles():
     assert len(c4) == 1 and c4[0]["pixels_compared"] == 1920 * 1080 and c4[0]["spp"] == 1024
     assert c4[0]["bit_identical"] and c4[0]["crc32_oracle"] == golden == c4[0]["crc32_gpu"]
     assert all(r["bit_identical"] and all(v["bit_identical"] for v in r.get("variants", [])) for r in recs)
+
+
+def test_closest_hit_does_not_depend_on_the_hierarchy(orc, scene_io):
+    """The closest hit is DEFINED as the minimum over all triangles of the Moeller-Trumbore t (ties: lower id), so that every hierarchy -
+    the oracle's, the product's three builders, quad and oct nodes - must find the same one.  That only holds if no triangle reports hits
+    outside its (padded) bounding box: slivers, whose test results are rounding noise, are collapsed at scene build (pt_oracle.c
+    orc_scene_create, csrc/pt_api.cpp pt_collapse_sliver).  Property test on the oracle alone: BVH walk == brute force over random
+    scenes with needles, coincident and degenerate triangles (the generator of tests/test_gpu_fuzz.py)."""
+    import test_gpu_fuzz as F
+
+    n_rays = 0
+    for seed in range(F.SEED0, F.SEED0 + 150):
+        rng = np.random.default_rng(seed)
+        ents, mats, scale, offset = F._random_scene(rng)
+        S = orc.Scene(scene_io.flatten_scene(ents, [("m%d" % i, m, "") for i, m in enumerate(mats)], None))
+        P = np.concatenate([m["vertices"][m["indices"]].reshape(-1, 3) for m, _ in ents])
+        for k in range(120):
+            if k % 2:
+                o = P[rng.integers(len(P))] + rng.normal(0, 1e-3, 3) * scale  # origins on / near the geometry, like secondary rays
+            else:
+                o = offset + rng.normal(0, 1, 3) * scale * 2.0
+            d = rng.normal(0, 1, 3)
+            if k % 7 == 0:
+                d[rng.integers(3)] = 0.0
+            d = (d / np.linalg.norm(d)).astype(np.float32)
+            a = S.intersect(np.float32(o), d, use_bvh=True)
+            b = S.intersect(np.float32(o), d, use_bvh=False)
+            assert a[0] == b[0] and (not a[0] or (np.float32(a[1:4]).view(np.uint32) == np.float32(b[1:4]).view(np.uint32)).all() and a[4] == b[4]), (seed, k, a, b)
+            n_rays += 1
+    assert n_rays == 150 * 120
