@@ -20,8 +20,15 @@ N_CASES = int(os.environ.get("PT_FUZZ_CASES", "40"))
 SEED0 = int(os.environ.get("PT_FUZZ_SEED", "20260405"))
 
 PATHS = [(), (("groups", 2),), (("groups", 0),), (("kernel", 1),), (("whole", 1),), (("whole", 0), ("express_permille", 80)), (("schedule", 0), ("chunk_spp", 3)),
-         (("fallback", 1),), (("box_exact", 1),), (("count", 1),), (("count", 1), ("quad", 0), ("groups", 0)), (("bvh", 1),), (("bvh", 2),), (("leaf", 1),), (("leaf", 7),)]
-DEFAULTS = {"groups": 1, "kernel": 2, "whole": -1, "express_permille": -1, "schedule": 1, "chunk_spp": 64, "fallback": 0, "box_exact": -1, "count": 0, "quad": 1}
+         (("fallback", 1),), (("box_exact", 1),), (("count", 1),), (("count", 1), ("quad", 0), ("groups", 0)), (("bvh", 1),), (("bvh", 2),), (("leaf", 1),), (("leaf", 7),),
+         # scheduler knobs (none may change an image): launch geometry, pre-pass, cost filter, chunking, express waves, top-up threshold, retuning
+         (("slots_per_wave", 64),), (("slots_per_wave", 104), ("blocks_per_cu", 2)), (("blocks_per_cu", 1),), (("prepass_spp", 1),), (("prepass_spp", 5), ("cost_radius", 0)),
+         (("cost_radius", 7),), (("spp_per_launch", 5),), (("schedule", 0), ("chunk_spp", 1), ("chunk_tail_min", 0)), (("sticky_pct", 1),), (("sticky_pct", 100),),
+         (("whole", 0), ("express_permille", 400), ("ns_express", 3)), (("tune0", 1),), (("tune0", 65),), (("adaptive", 0),), (("wide", 1),),
+         (("shard", 0),), (("shard", 1),), (("shard", 2),)]
+DEFAULTS = {"groups": 1, "kernel": 2, "whole": -1, "express_permille": -1, "schedule": 1, "chunk_spp": 64, "fallback": 0, "box_exact": -1, "count": 0, "quad": 1,
+            "slots_per_wave": 0, "blocks_per_cu": 0, "prepass_spp": 0, "cost_radius": 2, "spp_per_launch": 0, "chunk_tail_min": -1, "sticky_pct": -1, "ns_express": 8,
+            "tune0": 0, "adaptive": 1}
 
 
 def _bits(a):
@@ -107,11 +114,14 @@ def _random_camera(rng, scale, offset, W, H):
     return [float(x) for x in frm], [float(x) for x in centre], [float(x) for x in up], fov
 
 
-def _case(gpu, orc, scene_io, seed):
+def _case(gpu, orc, scene_io, seed, large=False):
     rng = np.random.default_rng(seed)
     ents, mats, scale, offset = _random_scene(rng)
     W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
     spp = int(rng.choice([1, 2, 7, 16, 33, 64, 130]))
+    if large:  # more pixels than the chip has path slots (393 216): tickets, rings, laggards, tiers with rounds, express waves at scale
+        W, H = int(rng.integers(500, 1300)), int(rng.integers(400, 900))
+        spp = int(rng.choice([4, 9, 20, 33, 48]))
     depth = int(rng.choice([1, 2, 4, 16, 31]))
     mode = int(rng.integers(0, 3))
     texs, mesh_tex, tex_by_mat = None, None, None
@@ -132,24 +142,41 @@ def _case(gpu, orc, scene_io, seed):
     cam = B.to_camera_data(frm, at, up, fov, W, H)
     ocam = orc.to_camera_data(tuple(frm), tuple(at), tuple(up), fov, W, H)
     path = PATHS[int(rng.integers(0, len(PATHS)))]
-    pre = {"bvh": ("bvh_builder", 3), "leaf": ("leaf_size", 4)}
+    if large and path and path[0][0] in ("kernel", "count"):
+        path = (("schedule", 0), ("chunk_spp", 2))  # (the slow instances are not what this variant is about)
+    pre = {"bvh": ("bvh_builder", 3), "leaf": ("leaf_size", 4), "wide": ("wide_leaves", 0)}
+    shard = None
+    for k, v in path:
+        if k == "shard":  # one rank's pixel tiles of a multi-GPU frame: exactly the full frame's values there, zero elsewhere
+            world = int(rng.integers(2, 10))
+            shard = (int(rng.integers(0, world)), world, int(rng.choice([1, 4, 16, 32])))
     try:
         for k, v in path:
             if k in pre:
                 gpu.set_option(pre[k][0], v)
         gpu.upload_scene(ents, mats, textures=texs, mesh_textures=mesh_tex, env=B.make_env(**env))
         for k, v in path:
-            if k not in pre:
+            if k not in pre and k != "shard":
                 gpu.set_option(k, v)
-        got, _ = gpu.render(cam, W, H, spp, depth)
+        if shard:
+            gpu.set_pixel_shard(*shard)
+        got, got8 = gpu.render(cam, W, H, spp, depth, want_rgba8=True)
     finally:
+        gpu.set_pixel_shard(0, 1, 16)
         for k, v in path:
             if k in pre:
                 gpu.set_option(*pre[k])
-            else:
+            elif k != "shard":
                 gpu.set_option(k, DEFAULTS[k])
     S = orc.Scene(scene_io.flatten_scene(ents, [("m%d" % i, m, "") for i, m in enumerate(mats)], tex_by_mat))
-    want, _, _ = S.render(ocam, orc.make_env(**env), W, H, spp, depth)
+    want, want8, _ = S.render(ocam, orc.make_env(**env), W, H, spp, depth, want_rgba8=True)
+    if shard:
+        own = np.zeros(W * H, bool)
+        own[B.shard_pixels(W, H, shard[2], shard[0], shard[1])] = True
+        own = own.reshape(H, W)[::-1]
+        want = np.where(own[..., None], want, np.float32(0.0))
+        want8 = np.where(own, want8, np.uint32(0))
+    assert (got8 == want8).all(), "fuzz case seed=%d: RGBA8 output differs (path %s)" % (seed, path)
     same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
     if not same.all():
         bad = np.argwhere(~same)
@@ -165,3 +192,15 @@ def test_random_scenes_bitwise(orc, scene_io):
         _case(gpu, orc, scene_io, seed)
         if (n + 1) % 100 == 0:
             print("fuzz: %d cases bit-identical" % (n + 1), flush=True)
+
+
+N_LARGE = int(os.environ.get("PT_FUZZ_LARGE", "8"))
+
+
+def test_random_large_frames_bitwise(orc, scene_io):
+    """The same generator at 200 000 - 1 100 000 pixels and 4-48 spp: most of these frames have more pixels than the chip has path slots, so the ticket
+    counters, the per-chunk rings with their cross-wave hand-offs, the tier plan with rounds and the express waves all run at scale -
+    with scenes whose pixels differ wildly in cost.  8 cases by default (~10 s); PT_FUZZ_LARGE=N."""
+    gpu = B.Context(0)
+    for n in range(N_LARGE):
+        _case(gpu, orc, scene_io, SEED0 + 5_000_000 + n, large=True)
