@@ -22,6 +22,17 @@ def gpu():
     ctx.close()
 
 
+def _host_threads():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -93,6 +104,74 @@ def test_deterministic_libm_bitwise(gpu, orc):
     y = rng.uniform(-3, 3, n).astype(np.float32)
     assert_bitwise(gpu.debug_eval("sqrt", x, 1)[:, 0], np.sqrt(x), "sqrt")
     assert_bitwise(gpu.debug_eval("div", np.stack([x, y], 1), 1)[:, 0], x / y, "div")
+
+
+@pytest.mark.skipif(os.environ.get("PT_LIBM_EXHAUSTIVE") != "1", reason="opt-in (PT_LIBM_EXHAUSTIVE=1): every float32 through every unary function, ~3 minutes")
+def test_deterministic_libm_exhaustive(gpu, orc):
+    """ALL 2^32 float32 bit patterns through sin, cos, tan, atan, asin, log, exp and sqrt on the GPU (pt_device.h) and in the oracle
+    (pt_oracle.c): identical bits everywhere (any NaN == any NaN; sin / cos / tan: everywhere below |x| = 2e9).  The two-argument functions (atan2, pow, division) get the cross
+    product of 4 096 special and random values (16.7 M pairs each).  Record: gpurun_out/libm_exhaustive.json."""
+    import json, time
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = _host_threads()
+    rec = {}
+    chunk = 1 << 26
+
+    def oracle_eval(fn, x, y=None):
+        parts = np.array_split(np.arange(x.size), threads * 4)
+        out = np.empty_like(x)
+
+        def work(idx):
+            out[idx[0]:idx[-1] + 1] = orc.dm(fn, x[idx[0]:idx[-1] + 1], None if y is None else y[idx[0]:idx[-1] + 1])
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, [p for p in parts if p.size]))
+        return out
+
+    for fn in ("sin", "cos", "tan", "atan", "asin", "log", "exp", "sqrt"):
+        t0 = time.perf_counter()
+        bad, bad_inside, smallest = 0, 0, float("inf")
+        for base in range(0, 1 << 32, chunk):
+            x = np.arange(base, base + chunk, dtype=np.uint64).astype(np.uint32).view(np.float32)
+            g = gpu.debug_eval(fn, x, 1)[:, 0]
+            w = oracle_eval(fn, x)
+            same = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+            if not same.all():
+                i = int(np.argmin(same))
+                bad += int((~same).sum())
+                with np.errstate(invalid="ignore"):
+                    inside = (~same) & (np.abs(x) < np.float32(2.0e9))
+                bad_inside += int(inside.sum())
+                smallest = min(smallest, float(np.abs(x[~same]).min()))
+                if bad_inside:
+                    print("%s: first difference at x = %r (bits %08x): gpu %r oracle %r" % (fn, x[i], int(x[i:i + 1].view(np.uint32)[0]), g[i], w[i]), flush=True)
+        rec[fn] = {"inputs": 1 << 32, "differences": bad, "differences_below_2e9": bad_inside, "smallest_differing_magnitude": None if bad == 0 else smallest,
+                   "seconds": round(time.perf_counter() - t0, 1)}
+        print(fn, rec[fn], flush=True)
+    rng = np.random.default_rng(4)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 0.5, 2.0, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38, 1e-20, 1e20, 0.99999994, 1.0000001,
+                        3.1415927, 1.5707964, 2.2, 0.45454547], np.float32)
+    vals = np.concatenate([special, rng.uniform(-4, 4, 2000), np.exp(rng.uniform(-80, 80, 1037)) * rng.choice([-1, 1], 1037), rng.integers(0, 1 << 32, 1037, dtype=np.uint64).astype(np.uint32).view(np.float32)]).astype(np.float32)
+    assert vals.size == 4096
+    a, b = np.meshgrid(vals, vals, indexing="ij")
+    a, b = np.ascontiguousarray(a.ravel()), np.ascontiguousarray(b.ravel())
+    for fn in ("atan2", "pow", "div"):
+        g = gpu.debug_eval(fn, np.stack([a, b], 1), 1)[:, 0]
+        w = oracle_eval(fn, a, b) if fn != "div" else a / b
+        same = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+        rec[fn] = {"inputs": int(a.size), "differences": int((~same).sum())}
+        if not same.all():
+            i = int(np.argmin(same))
+            print("%s: first difference at (%r, %r): gpu %r oracle %r" % (fn, a[i], b[i], g[i], w[i]), flush=True)
+        print(fn, rec[fn], flush=True)
+    out_path = os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "libm_exhaustive.json")
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(rec, f, indent=1)
+    # sin / cos / tan reduce their argument through an int conversion: beyond |x| = 2^31 * pi / 2 = 3.37e9 the conversion saturates differently on
+    # the two machines (the renderer's arguments are 2 pi u and a field of view: the contract's domain, pt_device.h); everything else: all inputs
+    assert all(rec[k]["differences"] == 0 for k in ("atan", "asin", "log", "exp", "sqrt", "atan2", "pow", "div")), rec
+    assert all(rec[k]["differences_below_2e9"] == 0 for k in ("sin", "cos", "tan")), rec
 
 
 def test_rng_kat_on_device(gpu, orc):
@@ -829,17 +908,6 @@ def test_c5_car_standin_full_size(gpu, orc, scene_io, procedural):
     _subset_check(a, S, orc, cam, orc.make_env(**env), W, H, 4096, 16, 160, 6)
     _whole_frame_check(gpu, S, orc, cam, orc.make_env(**env), W, H, 4, 16, "C5")
     print("C5 (counted) kernel_ms=%.1f Msamples/s=%.1f rays/sample=%.2f" % (st["kernel_ms"], W * H * 4096 / st["kernel_ms"] / 1e3, st["rays"] / st["samples"]))
-
-
-def _host_threads():
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
 
 
 @pytest.mark.skipif(os.environ.get("PT_FULL_FRAME_PARITY") != "1", reason="opt-in (PT_FULL_FRAME_PARITY=1): ~8 minutes of oracle time on 16 threads")
