@@ -233,3 +233,29 @@ def test_closest_hit_does_not_depend_on_the_hierarchy(orc, scene_io):
             assert a[0] == b[0] and (not a[0] or (np.float32(a[1:4]).view(np.uint32) == np.float32(b[1:4]).view(np.uint32)).all() and a[4] == b[4]), (seed, k, a, b)
             n_rays += 1
     assert n_rays == 150 * 120
+
+
+def test_oracle_image_is_the_same_with_and_without_its_hierarchy(orc, scene_io):
+    """Whole images of random scenes (tests/test_gpu_fuzz.py's generator) rendered by the oracle through its BVH and by brute force over all
+    triangles: bit-identical - the image-level form of the order-independence the parity claim rests on - and the same on 1 and 4 threads and
+    through the pixel-list entry point."""
+    import test_gpu_fuzz as F
+
+    for seed in range(F.SEED0 + 100, F.SEED0 + 130):
+        rng = np.random.default_rng(seed)
+        ents, mats, scale, offset = F._random_scene(rng)
+        W, H = int(rng.integers(4, 40)), int(rng.integers(4, 30))
+        S = orc.Scene(scene_io.flatten_scene(ents, [("m%d" % i, m, "") for i, m in enumerate(mats)], None))
+        frm, at, up, fov = F._random_camera(rng, scale, offset, W, H)
+        cam = orc.to_camera_data(tuple(frm), tuple(at), tuple(up), fov, W, H)
+        env = orc.make_env(use_auto=True, intensity=1.0)
+        a, _, _ = S.render(cam, env, W, H, 12, 8, use_bvh=True, threads=4)
+        b, _, _ = S.render(cam, env, W, H, 12, 8, use_bvh=False, threads=1)
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (seed, np.argwhere(~same)[:3])
+        ids = np.arange(W * H, dtype=np.uint32)[::3]
+        sub = np.zeros((H, W, 3), np.float32)
+        S.render(cam, env, W, H, 12, 8, pixel_list=ids, out=sub)
+        ys, xs = (H - 1 - ids // W), ids % W
+        s2 = (sub[ys, xs].view(np.uint32) == a[ys, xs].view(np.uint32)) | (np.isnan(sub[ys, xs]) & np.isnan(a[ys, xs]))
+        assert s2.all(), seed
