@@ -116,7 +116,10 @@ const char* pt_last_error(const pt_ctx* ctx);     /* ctx may be NULL (creation e
 int pt_abi_version(void);
 
 /* ---- scene (replaces bind_sbt_data + init_owl_world: application.cpp:184-294, :131-140) ----
- * Copies the meshes, builds the BVH2 on the host and uploads everything to HBM. */
+ * Copies the meshes, builds the BVH2 on the host and uploads everything to HBM.
+ * Closest hit = the minimum over all triangles of the Moeller-Trumbore t (ties: lower global triangle index), independent of the hierarchy;
+ * sliver triangles - height below 1e-5 of the longest edge, i.e. below ~100 ulp of their coordinates - are never hit (their test result
+ * would be rounding noise).  OptiX's watertight test gives such triangles a vanishing cross-section as well. */
 int pt_upload_scene(pt_ctx* ctx, const pt_mesh* meshes, int32_t n_meshes, const float* materials, int32_t n_materials,
                     const pt_texture* textures, int32_t n_textures, const int32_t* material_texture, const pt_env* env);
 /* material_texture: optional n_materials ints (texture index per material or <0).  NULL => derived from
