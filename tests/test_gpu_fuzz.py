@@ -204,3 +204,5 @@ def test_random_large_frames_bitwise(orc, scene_io):
     gpu = B.Context(0)
     for n in range(N_LARGE):
         _case(gpu, orc, scene_io, SEED0 + 5_000_000 + n, large=True)
+        if (n + 1) % 25 == 0:
+            print("fuzz (large frames): %d cases bit-identical" % (n + 1), flush=True)
