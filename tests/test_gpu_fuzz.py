@@ -114,7 +114,8 @@ def _random_camera(rng, scale, offset, W, H):
     return [float(x) for x in frm], [float(x) for x in centre], [float(x) for x in up], fov
 
 
-def _case(gpu, orc, scene_io, seed, large=False):
+def draw_case(seed, large=False):
+    """Everything one case consists of, drawn from `seed` in a fixed order (tools/fuzz_bisect.py and tools/fuzz_diag.py use it too)."""
     rng = np.random.default_rng(seed)
     ents, mats, scale, offset = _random_scene(rng)
     W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
@@ -139,17 +140,30 @@ def _case(gpu, orc, scene_io, seed, large=False):
         px = rng.integers(0, 256, (eh, ew, 3)).astype(np.uint32)
         env = dict(use_map=True, intensity=float(rng.uniform(0.2, 2.0)), env_map=(px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | (0xFF << 24)).astype(np.uint32))
     frm, at, up, fov = _random_camera(rng, scale, offset, W, H)
-    cam = B.to_camera_data(frm, at, up, fov, W, H)
-    ocam = orc.to_camera_data(tuple(frm), tuple(at), tuple(up), fov, W, H)
     path = PATHS[int(rng.integers(0, len(PATHS)))]
     if large and path and path[0][0] in ("kernel", "count"):
         path = (("schedule", 0), ("chunk_spp", 2))  # (the slow instances are not what this variant is about)
-    pre = {"bvh": ("bvh_builder", 3), "leaf": ("leaf_size", 4), "wide": ("wide_leaves", 0)}
     shard = None
     for k, v in path:
         if k == "shard":  # one rank's pixel tiles of a multi-GPU frame: exactly the full frame's values there, zero elsewhere
             world = int(rng.integers(2, 10))
             shard = (int(rng.integers(0, world)), world, int(rng.choice([1, 4, 16, 32])))
+    return dict(seed=seed, ents=ents, mats=mats, W=W, H=H, spp=spp, depth=depth, mode=mode, env=env, texs=texs, mesh_tex=mesh_tex, tex_by_mat=tex_by_mat,
+                camera=(frm, at, up, fov), path=path, shard=shard)
+
+
+def _case(gpu, orc, scene_io, seed, large=False, path=None):
+    c = draw_case(seed, large)
+    ents, mats, W, H, spp, depth, mode, env = c["ents"], c["mats"], c["W"], c["H"], c["spp"], c["depth"], c["mode"], c["env"]
+    texs, mesh_tex, tex_by_mat, shard = c["texs"], c["mesh_tex"], c["tex_by_mat"], c["shard"]
+    frm, at, up, fov = c["camera"]
+    if path is None:
+        path = c["path"]
+    else:
+        shard = None  # (tools/fuzz_diag.py: the same case through a path of the caller's choice)
+    cam = B.to_camera_data(frm, at, up, fov, W, H)
+    ocam = orc.to_camera_data(tuple(frm), tuple(at), tuple(up), fov, W, H)
+    pre = {"bvh": ("bvh_builder", 3), "leaf": ("leaf_size", 4), "wide": ("wide_leaves", 0)}
     try:
         for k, v in path:
             if k in pre:

@@ -11,25 +11,10 @@ from owl_path_tracer_amd.pyhost import scene_io, binding as B
 import test_gpu_fuzz as F
 
 seed = int(sys.argv[1])
-rng = np.random.default_rng(seed)
-ents, mats, scale, offset = F._random_scene(rng)
-W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
-spp = int(rng.choice([1, 2, 7, 16, 33, 64, 130])); depth = int(rng.choice([1, 2, 4, 16, 31])); mode = int(rng.integers(0, 3))
-texs, mesh_tex, tex_by_mat = None, None, None
-if rng.random() < 0.3:
-    h, w = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-    px = rng.integers(0, 256, (h, w, 3)).astype(np.uint32)
-    t = (px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | (0xFF << 24)).astype(np.uint32)
-    texs, mesh_tex, tex_by_mat = [t], [0 if mid == 0 else -1 for _, mid in ents], {0: t}
-if mode == 0:
-    env = dict(use_auto=True, intensity=float(rng.uniform(0.0, 2.0)))
-elif mode == 1:
-    env = dict(color=tuple(float(x) for x in rng.random(3)), intensity=float(rng.choice([0.0, 1.0, rng.uniform(0, 3)])))
-else:
-    eh, ew = int(rng.integers(1, 17)), int(rng.integers(1, 33))
-    px = rng.integers(0, 256, (eh, ew, 3)).astype(np.uint32)
-    env = dict(use_map=True, intensity=float(rng.uniform(0.2, 2.0)), env_map=(px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | (0xFF << 24)).astype(np.uint32))
-frm, at, up, fov = F._random_camera(rng, scale, offset, W, H)
+c = F.draw_case(seed, len(sys.argv) > 2)
+ents, mats, W, H, spp, depth, mode, env = c["ents"], c["mats"], c["W"], c["H"], c["spp"], c["depth"], c["mode"], c["env"]
+texs, mesh_tex, tex_by_mat = c["texs"], c["mesh_tex"], c["tex_by_mat"]
+frm, at, up, fov = c["camera"]
 print("case", seed, W, H, spp, depth, "env mode", mode, {k: (v if k != "env_map" else v.shape) for k, v in env.items()}, "tex", None if texs is None else texs[0].shape)
 print("camera", frm, at, up, fov)
 print("materials\n", mats)
