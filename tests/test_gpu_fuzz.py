@@ -198,8 +198,16 @@ def _case(gpu, orc, scene_io, seed, large=False, path=None):
                              % (seed, W, H, spp, depth, mode, path, sum(len(m["indices"]) for m, _ in ents), len(bad), same.size, bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
 
 
-def test_random_scenes_bitwise(orc, scene_io):
+def _context():
     gpu = B.Context(0)
+    for kv in os.environ.get("PT_FUZZ_OPTIONS", "").split():  # e.g. PT_LIB_PATH=.../libmi355pt_lobebins.so PT_FUZZ_OPTIONS="lobe_bins=1": a side build through the same cases
+        k, v = kv.split("=")
+        gpu.set_option(k, int(v))
+    return gpu
+
+
+def test_random_scenes_bitwise(orc, scene_io):
+    gpu = _context()
     only = os.environ.get("PT_FUZZ_ONLY")
     seeds = [int(only)] if only else [SEED0 + i for i in range(N_CASES)]
     for n, seed in enumerate(seeds):
@@ -215,7 +223,7 @@ def test_random_large_frames_bitwise(orc, scene_io):
     """The same generator at 200 000 - 1 100 000 pixels and 4-48 spp: most of these frames have more pixels than the chip has path slots, so the ticket
     counters, the per-chunk rings with their cross-wave hand-offs, the tier plan with rounds and the express waves all run at scale -
     with scenes whose pixels differ wildly in cost.  8 cases by default (~10 s); PT_FUZZ_LARGE=N."""
-    gpu = B.Context(0)
+    gpu = _context()
     for n in range(N_LARGE):
         _case(gpu, orc, scene_io, SEED0 + 5_000_000 + n, large=True)
         if (n + 1) % 25 == 0:
