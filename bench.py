@@ -28,6 +28,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool supports dmabuf IPC only (RCCL across processes fails with "hipIpcGetMemHandle: invalid argument" otherwise);
+# already exported on the boxes - set before anything touches HIP in case a launcher dropped it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
