@@ -98,6 +98,13 @@ int orc_render(const orc_scene* s, const orc_camera* cam, const orc_env* env, in
 int orc_trace_pixel(const orc_scene* s, const orc_camera* cam, const orc_env* env, int W, int H, int px, int py,
                     int max_samples, int max_depth, int use_bvh, float* per_sample_rgb, uint32_t* per_sample_state);
 
+/* Per-bounce log of ONE sample of one pixel (32 floats per bounce: origin, direction, hit flag, t u v, triangle, material, rng state before
+   sample_disney, local wo, f, pdf, local wi, lobe, throughput, rng state after, radiance, depth - layout at ORC_LOG_FLOATS in pt_oracle.c).
+   tools/fuzz_bisect.py replays the rows through the product's closest-hit and sample_disney debug ops to find where a differing sample
+   parts ways.  Returns the number of rows written (<= max_rows). */
+int orc_trace_sample(const orc_scene* s, const orc_camera* cam, const orc_env* env, int W, int H, int px, int py, int sample, int max_depth,
+                     int use_bvh, float* log, int max_rows);
+
 /* ---- unit hooks (vector tests) ---- */
 uint32_t orc_rng_init(uint32_t seed_u, uint32_t seed_v);        /* random.hpp:46-56 */
 float orc_rng_next(uint32_t* state);                            /* random.hpp:61-69 */
