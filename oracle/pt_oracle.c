@@ -1,5 +1,5 @@
 /*
- * pt_oracle.c -- CPU ORACLE (test infrastructure only; see pt_oracle.h header note: PARITY UNPINNED).
+ * pt_oracle.c -- CPU ORACLE (test infrastructure only; see pt_oracle.h header note: parity pinned by the reference's furnace images only, unpinned elsewhere).
  *
  * Plain-C restatement of the reference render loop.  Every function cites the reference
  * file:line it follows (paths relative to /root/reference/path_tracer/src unless stated).

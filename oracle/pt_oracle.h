@@ -6,11 +6,15 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
  * library (owl-path-tracer_amd/csrc) never includes, links or calls anything in oracle/.
  *
- * PARITY UNPINNED: the reference ships no golden vectors, known-answer tests or
- * fixtures for this path (unit_tests/path_tracer_test.cu:10-31 is a placeholder) and it
- * cannot be built here (needs nvcc, OptiX 7.4, OWL, fmt, nlohmann, tinyobj -- all absent).
- * The oracle is pinned only by the anchors recorded in SURVEY.md 8(a6)/8(c) (RNG integer
- * states: exact; three sample_disney anchors: ~1e-6 relative), see tests/test_oracle_anchors.py.
+ * PARITY PINNED ONLY IN PART, UNPINNED ELSEWHERE: the reference ships no golden vectors, known-answer
+ * tests or fixtures for this path (unit_tests/path_tracer_test.cu:10-31 is a placeholder) and it
+ * cannot be built here (needs nvcc, OptiX 7.4, OWL, fmt, nlohmann, tinyobj -- all absent), so there
+ * is no oracle/_ref.  What pins the oracle to the reference is what the reference itself rendered:
+ * the furnace images under thesis/assets/furnace-test (tests/golden/furnace_reference.json, ring means
+ * of the 8-bit values): camera, miss shader, diffuse lobe, the mirror limits of the specular and glass
+ * lobes, the rough GGX lobe at normal incidence, the quantiser - every ring within +-1 code - and the
+ * survey's RNG integer states (exact).  UNPINNED (no reference output exercises them): clearcoat, rough
+ * glass, sheen, oblique rough specular, Russian roulette, textures, the traversal.  DESIGN.md 2.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
